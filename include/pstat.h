@@ -1,0 +1,180 @@
+/*
+ * pstat.h -- C ABI of libpstat.so: the MI355X (gfx950) implementation of the fixed-force-ensemble
+ * MCMC hot path of grasingerm/polymer-stats.
+ *
+ * The reference exposes no FFI for this path: the whole of it lives inside one Julia function,
+ * mcmc(nsteps, pargs) (mcmc_eap_chain.jl:171-376), reached only through the command line
+ * (mcmc_eap_chain.jl:19-155).  This header is therefore the boundary a maintainer would bind with
+ * `ccall` when moving the step loop of that function onto the GPU; each entry point names the
+ * reference code it stands in for.  INTEGRATION.md shows the Julia-side binding.
+ *
+ * Conventions: plain C, caller-allocated output buffers, no callbacks, no exceptions across the ABI.
+ * Every function returns PSTAT_OK (0) or a negative pstat_status; pstat_strerror() names it and
+ * pstat_last_error() returns a thread-local detail string.  A handle is confined to one host thread
+ * at a time; distinct handles may be used concurrently.  There is no CPU fallback: without a HIP
+ * device pstat_create() fails with PSTAT_ERR_NO_DEVICE.
+ *
+ * One handle = `num_chains` independent Markov chains per case (chain-per-lane on the device), each
+ * one statistically identical to one reference run with `--num-inits 1`; results are pooled.
+ */
+#ifndef PSTAT_H
+#define PSTAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSTAT_ABI_VERSION 1
+
+typedef enum pstat_status {
+  PSTAT_OK = 0,
+  PSTAT_ERR_INVALID_ARG = -1,   /* bad parameter value (message in pstat_last_error)             */
+  PSTAT_ERR_NO_DEVICE = -2,     /* no HIP device / device index out of range                     */
+  PSTAT_ERR_HIP = -3,           /* a HIP runtime call failed                                     */
+  PSTAT_ERR_UNSUPPORTED = -4,   /* valid reference option that has no device implementation      */
+  PSTAT_ERR_NOMEM = -5,
+  PSTAT_ERR_BAD_CHECKPOINT = -6,
+  PSTAT_ERR_TOO_SMALL = -7      /* caller buffer too small; required size has been written back  */
+} pstat_status;
+
+/* --chain-type (mcmc_eap_chain.jl:25-28; inc/eap_chain.jl:81-87) */
+enum { PSTAT_DIELECTRIC = 0, PSTAT_POLAR = 1 };
+/* --energy-type (mcmc_eap_chain.jl:41-44; inc/eap_chain.jl:95-105) */
+enum { PSTAT_NONINTERACTING = 0, PSTAT_INTERACTING = 1, PSTAT_ISING = 2 };
+/* arithmetic of the device path: f32 state and transcendentals with f64 running sums, or f64
+ * throughout (the reference's Float64; bit-reproduces the CPU oracle's trajectory) */
+enum { PSTAT_F32 = 0, PSTAT_F64 = 1 };
+
+/* Flattened pargs::Dict (mcmc_eap_chain.jl:155) -- the keys the force-ensemble step loop reads. */
+typedef struct pstat_params {
+  /* physics: inc/eap_chain.jl:89-108 */
+  double E0, K1, K2, mu, kT, Fz, Fx, b;
+  /* proposal + adaptation: mcmc_eap_chain.jl:88-118,172-174,301-322 */
+  double phi_step, theta_step;
+  double adj_lb, adj_ub, adj_scale;
+  int64_t steps_per_adjust;
+  int64_t n;             /* --num-monomers                                                    */
+  int64_t num_chains;    /* chains per case on this handle (ours)                             */
+  uint64_t seed;         /* ours: the reference never seeds its RNG                           */
+  uint64_t chain_id0;    /* global id of this handle's first chain: shards over GPUs          */
+  int32_t chain_type;    /* PSTAT_DIELECTRIC | PSTAT_POLAR                                    */
+  int32_t energy_type;   /* PSTAT_NONINTERACTING | PSTAT_INTERACTING | PSTAT_ISING            */
+  int32_t do_flips;      /* --do-flips                                                        */
+  int32_t umbrella;      /* --umbrella-sampling                                               */
+  int32_t precision;     /* PSTAT_F32 | PSTAT_F64                                             */
+  int32_t device;        /* HIP device ordinal                                                */
+} pstat_params;
+
+/* Order of every 16-vector below = the columns of <prefix>_rolling.csv after "step"
+ * (mcmc_eap_chain.jl:259). */
+enum {
+  PSTAT_R1, PSTAT_R2, PSTAT_R3, PSTAT_R1SQ, PSTAT_R2SQ, PSTAT_R3SQ, PSTAT_RSQ,
+  PSTAT_P1, PSTAT_P2, PSTAT_P3, PSTAT_P1SQ, PSTAT_P2SQ, PSTAT_P3SQ, PSTAT_PSQ,
+  PSTAT_U, PSTAT_USQ, PSTAT_NOBS
+};
+
+/* Length (in doubles) of the device-side reduction vector of pstat_reduce_device():
+ *   [0]        number of chains reduced
+ *   [1..17]    sum over chains of the per-chain running mean of the 16 observables, then of the
+ *              per-chain acceptance ratio
+ *   [18..34]   sum over chains of the squares of those per-chain means
+ * Every entry is additive across handles/GPUs, so one all-reduce(SUM) merges ensembles. */
+#define PSTAT_NRED 35
+
+/* The ten stdout quantities of mcmc_eap_chain.jl:386-395 plus bookkeeping. */
+typedef struct pstat_summary {
+  double avg[PSTAT_NOBS];      /* pooled running averages, rolling.csv order                    */
+  double stderr_[PSTAT_NOBS];  /* across-chain standard error of each (0 if one chain)          */
+  double acceptance_ratio;     /* "AR": accepted / attempted over all chains and steps          */
+  double ar_stderr;
+  int64_t num_chains;
+  int64_t steps_per_chain;     /* steps recorded so far by every chain                          */
+  double attempted_updates;    /* num_chains * steps_per_chain                                  */
+} pstat_summary;
+
+typedef struct pstat_handle pstat_handle;
+
+int pstat_abi_version(void);
+const char *pstat_strerror(int status);
+const char *pstat_last_error(void);
+int pstat_device_count(void);
+
+/* Fills *p with the reference's option defaults (mcmc_eap_chain.jl:19-153). */
+void pstat_default_params(pstat_params *p);
+
+/* Replaces `chain = EAPChain(pargs); chain.U = U(chain)` and the averager construction
+ * (mcmc_eap_chain.jl:175-176,242-255; inc/eap_chain.jl:60-135): draws phi~U(0,2pi), theta~U(0,pi)
+ * for every chain on the device, derives r, p, U, zeroes the running sums.
+ * `cases`/`ncases`: ncases >= 1 parameter sets that differ only in the physics scalars
+ * (E0,K1,K2,mu,kT,Fz,Fx,b) -- a sweep grid run in one launch; every case gets num_chains chains.
+ * `stream`: a hipStream_t to launch on (e.g. torch's current stream) or NULL for the handle's own. */
+int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_handle **out);
+void pstat_destroy(pstat_handle *h);
+
+/* Replaces `nsteps` iterations of the step loop, mcmc_eap_chain.jl:276-328, for every chain:
+ * proposal draw (:277-280), move! (inc/eap_chain.jl:230-257), energy (inc/energy.jl:7-23),
+ * Metropolis (inc/acceptance.jl:29-39), step-size adaptation (:301-322), record! x 8 (:327-328).
+ * Asynchronous on the handle's stream. */
+int pstat_advance(pstat_handle *h, int64_t nsteps);
+int pstat_sync(pstat_handle *h);
+
+/* Replaces the re-initialisation between inits, mcmc_eap_chain.jl:352-361: every chain draws a
+ * fresh random configuration and adopts it if `force_init` or by metropolis_acc
+ * (inc/acceptance.jl:1-3); the within-init step counter restarts at 1. */
+int pstat_reinit(pstat_handle *h, int32_t force_init);
+
+/* Device-side reduction over the chains of case `icase` (or over all cases if icase < 0) into
+ * `dev_out`, a DEVICE pointer to PSTAT_NRED doubles owned by the caller (e.g. a torch tensor that
+ * is then all-reduced with RCCL).  Asynchronous on the handle's stream. */
+int pstat_reduce_device(pstat_handle *h, int32_t icase, double *dev_out);
+
+/* Replaces get_avg() over the 8 averagers as written to rolling.csv (mcmc_eap_chain.jl:334-346;
+ * inc/average.jl:38): pooled running averages of case `icase`, plus across-chain standard errors.
+ * Either output pointer may be NULL.  Synchronises. */
+int pstat_rolling(pstat_handle *h, int32_t icase, double avg_out[PSTAT_NOBS],
+                  double stderr_out[PSTAT_NOBS]);
+
+/* Replaces the trajectory.csv row source, mcmc_eap_chain.jl:330-333: r(3), p(3), U of one chain
+ * (`chain` counts over all cases: case = chain / num_chains).  Synchronises. */
+int pstat_microstate(pstat_handle *h, int64_t chain, double out[7]);
+
+/* The quantities printed at mcmc_eap_chain.jl:365,386-395.  Synchronises. */
+int pstat_summary_get(pstat_handle *h, int32_t icase, pstat_summary *out);
+
+/* Turns already-merged reduction vectors (host memory, PSTAT_NRED doubles, e.g. after an
+ * all-reduce over GPUs) into a summary.  Pure host arithmetic. */
+int pstat_summary_from_reduction(const double red[PSTAT_NRED], int64_t steps_per_chain,
+                                 pstat_summary *out);
+
+/* Per-chain accessors for tests and tooling (host buffers).  angles: theta[n] then phi[n] as
+ * doubles, radians; sums: the 16 per-chain running sums in rolling.csv order;
+ * counters: {accepted_total, steps_recorded, nacc_window, natt_window}; steps: {phi_step, theta_step}. */
+int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles /* [2n] */,
+                      double sums[PSTAT_NOBS], int64_t counters[4], double steps[2],
+                      uint32_t rng[4]);
+
+/* Checkpoint / resume of the full device state (angles, generators, step sizes, counters, running
+ * sums).  Call with buf == NULL to get the size.  The reference has no equivalent. */
+int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes);
+int pstat_restore(pstat_handle *h, const void *buf, size_t bytes);
+
+/* Introspection for benchmarks: kernel name, LDS bytes per workgroup, workgroups, resident
+ * workgroups per CU as given by the occupancy API for the sweep kernel of this handle. */
+typedef struct pstat_launch_info {
+  char kernel[64];
+  int32_t lds_bytes;
+  int32_t threads_per_block;
+  int32_t lanes_per_block;
+  int64_t blocks;
+  int32_t blocks_per_cu;
+  int32_t num_cus;
+} pstat_launch_info;
+int pstat_launch_info_get(pstat_handle *h, pstat_launch_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

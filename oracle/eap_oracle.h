@@ -1,0 +1,107 @@
+/*
+ * eap_oracle.h -- CPU restatement of the fixed-force-ensemble MCMC hot path of
+ * grasingerm/polymer-stats (mcmc_eap_chain.jl + inc/{eap_chain,dipole_response,
+ * energy,acceptance,average}.jl).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check in
+ * __graft_entry__.py and bench.py's cpu_baseline leg may load it.  The product
+ * (libpstat.so, polymer_stats_amd/) never links, imports or calls anything here.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors for this
+ * path, never seeds its RNG, and is Julia (no interpreter in this image), so no
+ * reference output exists to pin this restatement against.  It is pinned instead by
+ * closed-form single-monomer integrals (tests/golden/ni_closed_form.json), by
+ * hand-computable pair energies and by faithful-vs-incremental agreement.
+ *
+ * Citations "file:line" are relative to the reference tree.
+ */
+#ifndef EAP_ORACLE_H
+#define EAP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { EAP_DIELECTRIC = 0, EAP_POLAR = 1 };              /* --chain-type  */
+enum { EAP_NONINTERACTING = 0, EAP_INTERACTING = 1, EAP_ISING = 2 }; /* --energy-type */
+
+/* Flat mirror of the option table mcmc_eap_chain.jl:19-153 (hot-path subset). */
+typedef struct eap_params {
+  double E0, K1, K2, mu, kT, Fz, Fx, b;
+  double phi_step, theta_step;          /* mcmc_eap_chain.jl:88-98  */
+  double adj_lb, adj_ub, adj_scale;     /* :103-114 */
+  int64_t n;                            /* --num-monomers */
+  int64_t num_steps;                    /* --num-steps    */
+  int64_t num_inits;                    /* --num-inits    */
+  int64_t steps_per_adjust;             /* :115-118 */
+  int64_t stepout;                      /* :142-145 (rows only if buffers given) */
+  uint64_t seed;                        /* ours: the reference never seeds */
+  int32_t chain_type;
+  int32_t energy_type;
+  int32_t do_flips;
+  int32_t force_init;
+  int32_t umbrella;
+  int32_t reserved;
+} eap_params;
+
+/* Index order = the rolling.csv columns after "step" (mcmc_eap_chain.jl:259). */
+enum {
+  EAP_R1, EAP_R2, EAP_R3, EAP_R1SQ, EAP_R2SQ, EAP_R3SQ, EAP_RSQ,
+  EAP_P1, EAP_P2, EAP_P3, EAP_P1SQ, EAP_P2SQ, EAP_P3SQ, EAP_PSQ,
+  EAP_U, EAP_USQ, EAP_NOBS
+};
+
+typedef struct eap_result {
+  double sum[EAP_NOBS];   /* averager .value fields (inc/average.jl:9)       */
+  double norm;            /* averager .normalizer (count, or sum of 1/e^w)   */
+  int64_t nacc_total;     /* mcmc_eap_chain.jl:264,290                      */
+  int64_t nsteps_total;   /* num_inits * num_steps                          */
+  double phi_step, theta_step; /* step sizes after the last adaptation      */
+  double r[3], p[3], U;   /* final microstate (trajectory.csv columns)      */
+  uint32_t rng[4];        /* final generator state                          */
+} eap_result;
+
+/* Optional per-run outputs; any pointer may be NULL. */
+typedef struct eap_trace {
+  double *final_phi;      /* [n]  */
+  double *final_theta;    /* [n]  */
+  uint8_t *accepted;      /* [num_inits*num_steps] 1 = accepted              */
+  double *rolling_rows;   /* [rows][17]: step + 16 running averages          */
+  double *traj_rows;      /* [rows][8]:  step,r1,r2,r3,p1,p2,p3,U            */
+  int64_t max_rows;
+  int64_t rows_written;
+} eap_trace;
+
+/* --- random stream contract (shared with the HIP path by specification) --- */
+void eap_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void eap_rng_seed(uint64_t seed, uint64_t chain_id, uint32_t s[4]);
+uint32_t eap_xoshiro128pp_next(uint32_t s[4]);
+double eap_u01(uint32_t w);                       /* (w>>8) * 2^-24 in [0,1) */
+
+/* --- the two restatements --- */
+/* Literal algorithm: trial = deep copy, full prefix sum, full energy recompute,
+ * cached log-density in the acceptor (mcmc_eap_chain.jl:171-376). */
+int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, eap_trace *tr);
+/* Same Markov chain from the same stream with O(1) incremental energy for
+ * non-interacting/Ising and in-place update + pair recompute for interacting. */
+int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_trace *tr);
+
+/* Many independent chains (chain ids id0 .. id0+nchains-1), one per worker
+ * thread at a time, mirroring the reference's pmap process farm. mode: 0 faithful, 1 fast. */
+int eap_run_many(const eap_params *P, uint64_t id0, int64_t nchains, int nthreads,
+                 int mode, eap_result *out /* [nchains] */);
+
+/* Building blocks exported for hand-computable tests. */
+void eap_dipole(const eap_params *P, double cphi, double sphi, double cth, double sth,
+                double mu_out[3]);                                  /* dipole_response.jl:7-29 */
+double eap_pair_energy(int64_t n, const double *xs /*3xn col-major*/,
+                       const double *mus /*3xn*/, int ising);       /* eap_chain.jl:196-228 */
+double eap_chain_energy(const eap_params *P, const double *phi, const double *theta,
+                        double r_out[3], double p_out[3]);          /* energy.jl:7-23 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,498 @@
+// pstat_api.hip -- the C ABI of include/pstat.h on top of the kernels in pstat_kernels.hip.
+// Host-side only: owns device memory, validates options the way the reference's constructors do
+// (inc/eap_chain.jl:81-105 error() branches), sequences launches on one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/pstat.h"
+#include "pstat_device.h"
+
+using namespace pstat;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return fail(PSTAT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));          \
+  } while (0)
+
+constexpr uint64_t CKPT_MAGIC = 0x5053544154434b31ull;  // "PSTATCK1"
+
+struct Buffer {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct pstat_handle {
+  pstat_params base{};              // case 0's parameters (shared, non-physics fields)
+  std::vector<CaseConst> cases;     // host copy
+  CaseConst *d_cases = nullptr;
+  int ncases = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  LaunchCfg cfg{};
+  SweepArgs args{};
+  DevState S{};
+  std::vector<Buffer> bufs;         // every device allocation, in checkpoint order
+  double *d_partial = nullptr;      // reduction scratch
+  double *d_red = nullptr;          // PSTAT_NRED doubles
+  int64_t steps_recorded = 0;       // steps every chain has recorded so far (all inits)
+  int64_t step_in_init = 0;         // the reference's loop variable `step` (mcmc_eap_chain.jl:276)
+  size_t elem = 4;                  // sizeof(R)
+};
+
+namespace {
+
+int alloc(pstat_handle *h, void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) return fail(PSTAT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  h->bufs.push_back({*p, bytes});
+  return PSTAT_OK;
+}
+
+int validate(const pstat_params *c, int ncases) {
+  if (ncases < 1) return fail(PSTAT_ERR_INVALID_ARG, "ncases must be >= 1");
+  const pstat_params &b = c[0];
+  if (b.n < 1) return fail(PSTAT_ERR_INVALID_ARG, "num-monomers must be >= 1");
+  if (b.n > 0x7fffffff / 64) return fail(PSTAT_ERR_INVALID_ARG, "num-monomers too large");
+  if (b.num_chains < 1) return fail(PSTAT_ERR_INVALID_ARG, "num-chains must be >= 1");
+  if (b.chain_type != PSTAT_DIELECTRIC && b.chain_type != PSTAT_POLAR)
+    return fail(PSTAT_ERR_INVALID_ARG, "chain-type is not understood.");       // eap_chain.jl:86
+  if (b.energy_type < PSTAT_NONINTERACTING || b.energy_type > PSTAT_ISING)
+    return fail(PSTAT_ERR_INVALID_ARG, "energy-type is not understood.");      // eap_chain.jl:104
+  if (b.energy_type == PSTAT_INTERACTING)
+    return fail(PSTAT_ERR_UNSUPPORTED, "energy-type 'interacting' has no device kernel yet");
+  if (b.umbrella)
+    return fail(PSTAT_ERR_UNSUPPORTED, "umbrella sampling has no device kernel yet");
+  if (b.precision != PSTAT_F32 && b.precision != PSTAT_F64)
+    return fail(PSTAT_ERR_INVALID_ARG, "precision must be PSTAT_F32 or PSTAT_F64");
+  if (!(b.phi_step > 0) || !(b.theta_step > 0))
+    return fail(PSTAT_ERR_INVALID_ARG, "phi-step and theta-step must be > 0");
+  if (!(b.adj_scale > 0)) return fail(PSTAT_ERR_INVALID_ARG, "step-adjust-scale must be > 0");
+  for (int i = 0; i < ncases; ++i) {
+    const pstat_params &p = c[i];
+    if (!(p.kT > 0)) return fail(PSTAT_ERR_INVALID_ARG, "kT must be > 0 (case %d)", i);
+    if (!std::isfinite(p.E0) || !std::isfinite(p.K1) || !std::isfinite(p.K2) || !std::isfinite(p.mu) ||
+        !std::isfinite(p.Fz) || !std::isfinite(p.Fx) || !std::isfinite(p.b))
+      return fail(PSTAT_ERR_INVALID_ARG, "non-finite physics parameter (case %d)", i);
+    if (p.n != b.n || p.num_chains != b.num_chains || p.chain_type != b.chain_type ||
+        p.energy_type != b.energy_type || p.do_flips != b.do_flips || p.umbrella != b.umbrella ||
+        p.precision != b.precision || p.device != b.device || p.phi_step != b.phi_step ||
+        p.theta_step != b.theta_step || p.adj_lb != b.adj_lb || p.adj_ub != b.adj_ub ||
+        p.adj_scale != b.adj_scale || p.steps_per_adjust != b.steps_per_adjust)
+      return fail(PSTAT_ERR_INVALID_ARG, "case %d differs from case 0 in a non-physics field", i);
+  }
+  return PSTAT_OK;
+}
+
+int trig_mode_from_env() {
+  const char *e = getenv("PSTAT_TRIG");
+  if (!e) return 2;
+  int v = atoi(e);
+  return (v >= 0 && v <= 2) ? v : 2;
+}
+
+int set_device(pstat_handle *h) {
+  HIP_TRY(hipSetDevice(h->device));
+  return PSTAT_OK;
+}
+
+int reduce_to_host(pstat_handle *h, int icase, double red[PSTAT_NRED]) {
+  int rc = pstat_reduce_device(h, icase, h->d_red);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(red, h->d_red, sizeof(double) * PSTAT_NRED, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return PSTAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pstat_abi_version(void) { return PSTAT_ABI_VERSION; }
+
+const char *pstat_strerror(int status) {
+  switch (status) {
+    case PSTAT_OK: return "ok";
+    case PSTAT_ERR_INVALID_ARG: return "invalid argument";
+    case PSTAT_ERR_NO_DEVICE: return "no HIP device";
+    case PSTAT_ERR_HIP: return "HIP runtime error";
+    case PSTAT_ERR_UNSUPPORTED: return "option not supported on the device path";
+    case PSTAT_ERR_NOMEM: return "out of device memory";
+    case PSTAT_ERR_BAD_CHECKPOINT: return "checkpoint does not match this handle";
+    case PSTAT_ERR_TOO_SMALL: return "buffer too small";
+    default: return "unknown status";
+  }
+}
+
+const char *pstat_last_error(void) { return g_err; }
+
+int pstat_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void pstat_default_params(pstat_params *p) {
+  // mcmc_eap_chain.jl:19-153
+  std::memset(p, 0, sizeof *p);
+  p->E0 = 0.0; p->K1 = 1.0; p->K2 = 0.0; p->mu = 1e-2; p->kT = 1.0;
+  p->Fz = 0.0; p->Fx = 0.0; p->b = 1.0;
+  p->phi_step = 3 * M_PI / 8; p->theta_step = 3 * M_PI / 16;
+  p->adj_lb = 0.15; p->adj_ub = 0.55; p->adj_scale = 1.1;
+  p->steps_per_adjust = 2500;
+  p->n = 100;
+  p->num_chains = 1;
+  p->seed = 0; p->chain_id0 = 0;
+  p->chain_type = PSTAT_DIELECTRIC; p->energy_type = PSTAT_NONINTERACTING;
+  p->do_flips = 0; p->umbrella = 0;
+  p->precision = PSTAT_F32; p->device = 0;
+}
+
+int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_handle **out) {
+  if (!cases || !out) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  int rc = validate(cases, ncases);
+  if (rc) return rc;
+  int ndev = pstat_device_count();
+  if (ndev < 1) return fail(PSTAT_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
+  if (cases[0].device < 0 || cases[0].device >= ndev)
+    return fail(PSTAT_ERR_NO_DEVICE, "device %d out of range (have %d)", cases[0].device, ndev);
+
+  pstat_handle *h = new (std::nothrow) pstat_handle;
+  if (!h) return fail(PSTAT_ERR_NOMEM, "host allocation failed");
+  h->base = cases[0];
+  h->ncases = ncases;
+  h->device = cases[0].device;
+  h->elem = cases[0].precision == PSTAT_F64 ? 8 : 4;
+  for (int i = 0; i < ncases; ++i) {
+    const pstat_params &p = cases[i];
+    h->cases.push_back({p.E0, p.K1, p.K2, p.mu, p.kT, p.Fz, p.Fx, p.b, p.seed, p.chain_id0});
+  }
+  bool any_fx = false;
+  for (auto &c : h->cases) any_fx = any_fx || c.Fx != 0.0;
+  h->cfg = {h->base.precision, h->base.chain_type, h->base.energy_type, h->base.do_flips ? 1 : 0,
+            h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, trig_mode_from_env()};
+
+  const int lanes = choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
+  if (lanes == 0) {
+    delete h;
+    return fail(PSTAT_ERR_UNSUPPORTED, "num-monomers = %lld does not fit the 160 KiB LDS of a CU",
+                (long long)cases[0].n);
+  }
+  SweepArgs &A = h->args;
+  A.n = h->base.n;
+  A.chains_per_case = h->base.num_chains;
+  A.blocks_per_case = (h->base.num_chains + lanes - 1) / lanes;
+  A.nsteps = 0; A.step0 = 0;
+  A.steps_per_adjust = h->base.steps_per_adjust;
+  A.adj_lb = h->base.adj_lb; A.adj_ub = h->base.adj_ub; A.adj_scale = h->base.adj_scale;
+  A.lanes = lanes;
+  A.adaptive = (h->base.adj_scale != 1.0 && h->base.steps_per_adjust > 0) ? 1 : 0;  // mcmc_eap_chain.jl:302
+  if ((int64_t)A.blocks_per_case * ncases > 0x7fffffffLL) {
+    delete h;
+    return fail(PSTAT_ERR_INVALID_ARG, "too many chains for one launch");
+  }
+
+#define CREATE_TRY(expr)            \
+  do {                              \
+    int _rc = (expr);               \
+    if (_rc) { pstat_destroy(h); return _rc; } \
+  } while (0)
+#define CREATE_HIP(expr)                                                                   \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      pstat_destroy(h);                                                                    \
+      return fail(PSTAT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));           \
+    }                                                                                      \
+  } while (0)
+
+  CREATE_HIP(hipSetDevice(h->device));
+  if (stream) {
+    h->stream = (hipStream_t)stream;
+  } else {
+    CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  DevState &S = h->S;
+  const int64_t C = (int64_t)ncases * h->base.num_chains;
+  S.C = C;
+  const size_t n = (size_t)h->base.n, Cz = (size_t)C;
+  // checkpoint order = allocation order
+  CREATE_TRY(alloc(h, &S.ang, 2 * n * Cz * h->elem));
+  CREATE_TRY(alloc(h, (void **)&S.rng, 4 * Cz * sizeof(uint32_t)));
+  CREATE_TRY(alloc(h, (void **)&S.stepsz, 2 * Cz * sizeof(double)));
+  CREATE_TRY(alloc(h, (void **)&S.win, 2 * Cz * sizeof(int32_t)));
+  CREATE_TRY(alloc(h, (void **)&S.nacc_total, Cz * sizeof(int64_t)));
+  CREATE_TRY(alloc(h, (void **)&S.obs, NOBS_STATE * Cz * sizeof(double)));
+  CREATE_TRY(alloc(h, (void **)&S.sums, NSUMS * Cz * sizeof(double)));
+  CREATE_TRY(alloc(h, (void **)&S.wnorm, Cz * sizeof(double)));
+  CREATE_TRY(alloc(h, (void **)&S.lag, Cz * sizeof(double)));
+  const size_t nstate = h->bufs.size();
+  CREATE_TRY(alloc(h, &S.ang_tmp, 2 * n * Cz * h->elem));
+  CREATE_TRY(alloc(h, (void **)&h->d_cases, sizeof(CaseConst) * (size_t)ncases));
+  CREATE_TRY(alloc(h, (void **)&h->d_partial, sizeof(double) * reduce_scratch_doubles()));
+  CREATE_TRY(alloc(h, (void **)&h->d_red, sizeof(double) * PSTAT_NRED));
+  (void)nstate;
+  CREATE_HIP(hipMemcpyAsync(h->d_cases, h->cases.data(), sizeof(CaseConst) * (size_t)ncases,
+                            hipMemcpyHostToDevice, h->stream));
+  CREATE_HIP(launch_init(h->cfg, h->args, h->S, h->d_cases, h->base.phi_step, h->base.theta_step, h->stream));
+  CREATE_HIP(hipStreamSynchronize(h->stream));  // h->cases must outlive the copy; also surfaces faults here
+#undef CREATE_TRY
+#undef CREATE_HIP
+  *out = h;
+  return PSTAT_OK;
+}
+
+void pstat_destroy(pstat_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto &b : h->bufs) (void)hipFree(b.ptr);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int pstat_advance(pstat_handle *h, int64_t nsteps) {
+  if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  if (nsteps < 0) return fail(PSTAT_ERR_INVALID_ARG, "nsteps must be >= 0");
+  if (nsteps == 0) return PSTAT_OK;
+  int rc = set_device(h);
+  if (rc) return rc;
+  // per-launch window counters are 32-bit
+  const int64_t max_seg = 1ll << 30;
+  while (nsteps > 0) {
+    const int64_t seg = nsteps < max_seg ? nsteps : max_seg;
+    h->args.nsteps = seg;
+    h->args.step0 = h->step_in_init;
+    HIP_TRY(launch_sweep(h->cfg, h->args, h->S, h->d_cases, h->ncases, h->stream));
+    h->step_in_init += seg;
+    h->steps_recorded += seg;
+    nsteps -= seg;
+  }
+  return PSTAT_OK;
+}
+
+int pstat_sync(pstat_handle *h) {
+  if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return PSTAT_OK;
+}
+
+int pstat_reinit(pstat_handle *h, int32_t force_init) {
+  if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(launch_reinit(h->cfg, h->args, h->S, h->d_cases, force_init, h->stream));
+  h->step_in_init = 0;
+  return PSTAT_OK;
+}
+
+int pstat_reduce_device(pstat_handle *h, int32_t icase, double *dev_out) {
+  if (!h || !dev_out) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  if (icase >= h->ncases) return fail(PSTAT_ERR_INVALID_ARG, "case %d out of range", icase);
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int64_t per = h->base.num_chains;
+  const int64_t c0 = icase < 0 ? 0 : icase * per;
+  const int64_t c1 = icase < 0 ? h->S.C : c0 + per;
+  HIP_TRY(launch_reduce(h->S, c0, c1, h->steps_recorded, h->cfg.umbrella, h->d_partial, dev_out, h->stream));
+  return PSTAT_OK;
+}
+
+int pstat_summary_from_reduction(const double red[PSTAT_NRED], int64_t steps_per_chain,
+                                 pstat_summary *out) {
+  if (!red || !out) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  std::memset(out, 0, sizeof *out);
+  const double C = red[0];
+  out->num_chains = (int64_t)std::llround(C);
+  out->steps_per_chain = steps_per_chain;
+  out->attempted_updates = C * (double)steps_per_chain;
+  if (C < 1) return PSTAT_OK;
+  for (int q = 0; q < 17; ++q) {
+    const double mean = red[1 + q] / C;
+    double se = 0.0;
+    if (C > 1) {
+      double var = (red[18 + q] / C - mean * mean) * C / (C - 1);  // unbiased across-chain variance
+      se = var > 0 ? std::sqrt(var / C) : 0.0;
+    }
+    if (q < PSTAT_NOBS) { out->avg[q] = mean; out->stderr_[q] = se; }
+    else { out->acceptance_ratio = mean; out->ar_stderr = se; }
+  }
+  return PSTAT_OK;
+}
+
+int pstat_summary_get(pstat_handle *h, int32_t icase, pstat_summary *out) {
+  if (!h || !out) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  double red[PSTAT_NRED];
+  int rc = reduce_to_host(h, icase, red);
+  if (rc) return rc;
+  return pstat_summary_from_reduction(red, h->steps_recorded, out);
+}
+
+int pstat_rolling(pstat_handle *h, int32_t icase, double avg_out[PSTAT_NOBS],
+                  double stderr_out[PSTAT_NOBS]) {
+  pstat_summary s;
+  int rc = pstat_summary_get(h, icase, &s);
+  if (rc) return rc;
+  if (avg_out) std::memcpy(avg_out, s.avg, sizeof s.avg);
+  if (stderr_out) std::memcpy(stderr_out, s.stderr_, sizeof s.stderr_);
+  return PSTAT_OK;
+}
+
+int pstat_microstate(pstat_handle *h, int64_t chain, double out[7]) {
+  if (!h || !out) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  if (chain < 0 || chain >= h->S.C) return fail(PSTAT_ERR_INVALID_ARG, "chain out of range");
+  int rc = set_device(h);
+  if (rc) return rc;
+  // obs is [NOBS_STATE][C]: a strided gather of 7 doubles
+  HIP_TRY(hipMemcpy2DAsync(out, sizeof(double), h->S.obs + chain, sizeof(double) * (size_t)h->S.C,
+                           sizeof(double), 7, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return PSTAT_OK;
+}
+
+int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sums[PSTAT_NOBS],
+                      int64_t counters[4], double steps[2], uint32_t rng[4]) {
+  if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  if (chain < 0 || chain >= h->S.C) return fail(PSTAT_ERR_INVALID_ARG, "chain out of range");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const size_t C = (size_t)h->S.C, n = (size_t)h->base.n;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (angles) {
+    std::vector<unsigned char> tmp(2 * n * h->elem);
+    HIP_TRY(hipMemcpy2D(tmp.data(), h->elem, (char *)h->S.ang + (size_t)chain * h->elem, C * h->elem,
+                        h->elem, 2 * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < 2 * n; ++i)
+      angles[i] = h->elem == 8 ? ((double *)tmp.data())[i] : (double)((float *)tmp.data())[i];
+  }
+  if (sums) {
+    double s[NSUMS];
+    HIP_TRY(hipMemcpy2D(s, sizeof(double), h->S.sums + chain, C * sizeof(double), sizeof(double), NSUMS,
+                        hipMemcpyDeviceToHost));
+    sums[PSTAT_R1] = s[S_R1]; sums[PSTAT_R2] = s[S_R2]; sums[PSTAT_R3] = s[S_R3];
+    sums[PSTAT_R1SQ] = s[S_R1SQ]; sums[PSTAT_R2SQ] = s[S_R2SQ]; sums[PSTAT_R3SQ] = s[S_R3SQ];
+    sums[PSTAT_RSQ] = s[S_R1SQ] + s[S_R2SQ] + s[S_R3SQ];
+    sums[PSTAT_P1] = s[S_P1]; sums[PSTAT_P2] = s[S_P2]; sums[PSTAT_P3] = s[S_P3];
+    sums[PSTAT_P1SQ] = s[S_P1SQ]; sums[PSTAT_P2SQ] = s[S_P2SQ]; sums[PSTAT_P3SQ] = s[S_P3SQ];
+    sums[PSTAT_PSQ] = s[S_P1SQ] + s[S_P2SQ] + s[S_P3SQ];
+    sums[PSTAT_U] = s[S_U]; sums[PSTAT_USQ] = s[S_USQ];
+  }
+  if (counters) {
+    int32_t w[2];
+    int64_t tot;
+    HIP_TRY(hipMemcpy2D(w, sizeof(int32_t), h->S.win + chain, C * sizeof(int32_t), sizeof(int32_t), 2,
+                        hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&tot, h->S.nacc_total + chain, sizeof tot, hipMemcpyDeviceToHost));
+    counters[0] = tot; counters[1] = h->steps_recorded; counters[2] = w[0]; counters[3] = w[1];
+  }
+  if (steps)
+    HIP_TRY(hipMemcpy2D(steps, sizeof(double), h->S.stepsz + chain, C * sizeof(double), sizeof(double), 2,
+                        hipMemcpyDeviceToHost));
+  if (rng)
+    HIP_TRY(hipMemcpy2D(rng, sizeof(uint32_t), h->S.rng + chain, C * sizeof(uint32_t), sizeof(uint32_t), 4,
+                        hipMemcpyDeviceToHost));
+  return PSTAT_OK;
+}
+
+// checkpoint image: header, then the nine state buffers in allocation order
+struct CkptHeader {
+  uint64_t magic;
+  int64_t n, C, ncases, steps_recorded, step_in_init;
+  int32_t precision, chain_type, energy_type, reserved;
+};
+static const int kStateBuffers = 9;
+
+int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes) {
+  if (!h || !bytes) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  size_t need = sizeof(CkptHeader);
+  for (int i = 0; i < kStateBuffers; ++i) need += h->bufs[i].bytes;
+  if (!buf) { *bytes = need; return PSTAT_OK; }
+  if (*bytes < need) { *bytes = need; return fail(PSTAT_ERR_TOO_SMALL, "checkpoint needs %zu bytes", need); }
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  CkptHeader hd{CKPT_MAGIC, h->base.n, h->S.C, h->ncases, h->steps_recorded, h->step_in_init,
+                h->base.precision, h->base.chain_type, h->base.energy_type, 0};
+  char *q = (char *)buf;
+  std::memcpy(q, &hd, sizeof hd);
+  q += sizeof hd;
+  for (int i = 0; i < kStateBuffers; ++i) {
+    HIP_TRY(hipMemcpy(q, h->bufs[i].ptr, h->bufs[i].bytes, hipMemcpyDeviceToHost));
+    q += h->bufs[i].bytes;
+  }
+  *bytes = need;
+  return PSTAT_OK;
+}
+
+int pstat_restore(pstat_handle *h, const void *buf, size_t bytes) {
+  if (!h || !buf) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  size_t need = sizeof(CkptHeader);
+  for (int i = 0; i < kStateBuffers; ++i) need += h->bufs[i].bytes;
+  if (bytes < need) return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint is %zu bytes, handle needs %zu", bytes, need);
+  CkptHeader hd;
+  std::memcpy(&hd, buf, sizeof hd);
+  if (hd.magic != CKPT_MAGIC || hd.n != h->base.n || hd.C != h->S.C || hd.ncases != h->ncases ||
+      hd.precision != h->base.precision || hd.chain_type != h->base.chain_type ||
+      hd.energy_type != h->base.energy_type)
+    return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint header does not match this handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const char *q = (const char *)buf + sizeof hd;
+  for (int i = 0; i < kStateBuffers; ++i) {
+    HIP_TRY(hipMemcpy(h->bufs[i].ptr, q, h->bufs[i].bytes, hipMemcpyHostToDevice));
+    q += h->bufs[i].bytes;
+  }
+  h->steps_recorded = hd.steps_recorded;
+  h->step_in_init = hd.step_in_init;
+  return PSTAT_OK;
+}
+
+int pstat_launch_info_get(pstat_handle *h, pstat_launch_info *out) {
+  if (!h || !out) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  std::memset(out, 0, sizeof *out);
+  int lds = 0, bpc = 0;
+  const char *name = "";
+  HIP_TRY(sweep_kernel_info(h->cfg, h->args, &lds, &bpc, &name));
+  std::snprintf(out->kernel, sizeof out->kernel, "%s", name);
+  out->lds_bytes = lds;
+  out->threads_per_block = 64;
+  out->lanes_per_block = h->args.lanes;
+  out->blocks = h->args.blocks_per_case * h->ncases;
+  out->blocks_per_cu = bpc;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+  out->num_cus = prop.multiProcessorCount;
+  return PSTAT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+// pstat_device.h -- internal layout shared by the HIP kernels and the C-ABI host code.
+// Not part of the public interface (that is include/pstat.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pstat {
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident state of one handle.  Everything is struct-of-arrays over the chain index c
+// (fastest-varying), so that the 64 lanes of a wave -- 64 consecutive chains -- touch 64
+// consecutive elements: every spill/fill of chain state is a fully coalesced 256/512-byte access.
+// C = ncases * chains_per_case.
+// ---------------------------------------------------------------------------------------------
+enum { OBS_R1 = 0, OBS_R2, OBS_R3, OBS_P1, OBS_P2, OBS_P3, OBS_U, OBS_USUM, NOBS_STATE };
+// per-chain running sums kept on the device; r.r and p.p are the sums of their components
+enum { S_R1 = 0, S_R2, S_R3, S_R1SQ, S_R2SQ, S_R3SQ, S_P1, S_P2, S_P3, S_P1SQ, S_P2SQ, S_P3SQ,
+       S_U, S_USQ, NSUMS };
+
+struct DevState {
+  void *ang;            // R  [2][n][C]   plane 0 = theta, plane 1 = phi (radians)
+  void *ang_tmp;        // R  [2][n][C]   scratch for re-initialisation
+  uint32_t *rng;        // u32[4][C]      xoshiro128++ state
+  double *stepsz;       // f64[2][C]      phi_step, theta_step (mcmc_eap_chain.jl:172)
+  int32_t *win;         // i32[2][C]      nacc, natt since the last adaptation (:263,265)
+  int64_t *nacc_total;  // i64[C]         (:264)
+  double *obs;          // f64[NOBS_STATE][C]  r, p, U, sum(u) of the current microstate
+  double *sums;         // f64[NSUMS][C]  averager .value fields (inc/average.jl:9)
+  double *wnorm;        // f64[C]         averager .normalizer under umbrella sampling
+  double *lag;          // f64[C]         acceptor's cached log-pi minus the chain's own (re-init)
+  int64_t C;
+};
+
+struct CaseConst {      // physics scalars of one case (inc/eap_chain.jl:89-108)
+  double E0, K1, K2, mu, kT, Fz, Fx, b;
+  uint64_t seed, chain_id0;
+};
+
+struct SweepArgs {
+  int64_t n;
+  int64_t chains_per_case;
+  int64_t blocks_per_case;
+  int64_t nsteps;            // steps to run in this launch
+  int64_t step0;             // steps already done in the current init
+  int64_t steps_per_adjust;
+  double adj_lb, adj_ub, adj_scale;
+  int32_t lanes;             // chains per workgroup (64, or fewer when n is too long for LDS)
+  int32_t adaptive;          // adj_scale != 1 && steps_per_adjust > 0
+};
+
+// ---------------------------------------------------------------------------------------------
+// Random stream contract (restated, not shared, in oracle/eap_oracle.c):
+//   xoshiro128++ seeded by Philox4x32-10(key = seed, ctr = (chain_lo, chain_hi, 0x5eed, 0));
+//   u(w) = (w >> 8) * 2^-24;  idx = mulhi32(w, n).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int round = 0; round < 10; ++round) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct Xoshiro128pp {
+  uint32_t s0, s1, s2, s3;
+  __host__ __device__ inline void seed(uint64_t seed, uint64_t chain_id) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)chain_id, (uint32_t)(chain_id >> 32), 0x5eedu, 0u,
+                  (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    if ((o[0] | o[1] | o[2] | o[3]) == 0u) o[0] = 1u;
+    s0 = o[0]; s1 = o[1]; s2 = o[2]; s3 = o[3];
+  }
+  __host__ __device__ inline uint32_t next() {
+    uint32_t a = s0 + s3;
+    uint32_t result = ((a << 7) | (a >> 25)) + s0;
+    uint32_t t = s1 << 9;
+    s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
+    s2 ^= t;
+    s3 = (s3 << 11) | (s3 >> 21);
+    return result;
+  }
+};
+
+// host-callable launchers implemented in pstat_kernels.hip; all asynchronous on `stream`
+struct LaunchCfg {
+  int precision, chain_type, energy_type, do_flips, umbrella, has_fx, trig_mode;
+};
+hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
+                       const CaseConst *cases, double phi_step, double theta_step,
+                       hipStream_t stream);
+hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
+                        const CaseConst *cases, int ncases, hipStream_t stream);
+hipError_t launch_reinit(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
+                         const CaseConst *cases, int force_init, hipStream_t stream);
+// reduction of chains [c0, c1) into out[PSTAT_NRED]; partial = scratch of reduce_scratch_doubles()
+hipError_t launch_reduce(const DevState &s, int64_t c0, int64_t c1, int64_t steps_recorded,
+                         int umbrella, double *partial, double *out, hipStream_t stream);
+size_t reduce_scratch_doubles();
+// LDS bytes and kernel attributes of the sweep kernel chosen for cfg
+hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
+                             int *blocks_per_cu, const char **name);
+int choose_lanes(int precision, int64_t n, int energy_type);
+
+}  // namespace pstat

@@ -1,0 +1,608 @@
+// pstat_kernels.hip -- gfx950 (CDNA4) kernels for the fixed-force MCMC hot path.
+//
+// Mapping: ONE INDEPENDENT MARKOV CHAIN PER WAVEFRONT LANE.  A workgroup is
+// a single wave64; lane l of workgroup g owns chain g*lanes + l for the whole launch.
+//   * the chain's orientation angles (theta_i, phi_i), i < n, live in LDS as [monomer][lane] R2
+//     pairs: lane l only ever touches column l, so no barrier or cross-lane traffic is needed and a
+//     per-lane random monomer index is bank-conflict-free (ds_read_b64: bank = (2*lane + k) mod 64);
+//   * the generator (xoshiro128++), step sizes, adaptation counters, end-to-end vector r, dipole p,
+//     energy U and the running sums stay in registers;
+//   * HBM is touched only to fill LDS/registers at launch start and to spill them at the end.
+// There is no dense contraction anywhere on this path, hence no MFMA.
+//
+// Reference semantics implemented (file:line relative to the reference tree):
+//   proposal draw ............ mcmc_eap_chain.jl:277-280
+//   move! (force ensemble) ... inc/eap_chain.jl:230-257   (O(1) energy difference instead of the
+//                               deep copy :137-163 + full recompute :252-254)
+//   dipole response .......... inc/dipole_response.jl:7-29
+//   energies ................. inc/energy.jl:7-23, inc/eap_chain.jl:53,215-228
+//   Metropolis ............... inc/acceptance.jl:18-39
+//   adaptation ............... mcmc_eap_chain.jl:301-322
+//   averagers ................ inc/average.jl:38-48,63-67,99-124; mcmc_eap_chain.jl:242-255,327-328
+#include "pstat_device.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/pstat.h"
+
+namespace pstat {
+
+// ------------------------------------------------------------------------------------------ math
+
+template <typename R> struct Vec2;
+template <> struct Vec2<float> { using type = float2; };
+template <> struct Vec2<double> { using type = double2; };
+
+template <typename R> struct K;  // constants
+template <> struct K<float> {
+  static constexpr float pi = 3.14159274101257324f;  // (float)pi: > pi, so sin(pi) < 0 => clamp rejects
+  static constexpr float two_pi = 6.28318548202514648f;
+  static constexpr float half_pi = 1.57079637050628662f;
+};
+template <> struct K<double> {
+  static constexpr double pi = 3.14159265358979323846;
+  static constexpr double two_pi = 6.28318530717958647692;
+  static constexpr double half_pi = 1.57079632679489661923;
+};
+
+// TRIG modes for the f32 path: 0 = OCML sincosf (<= 2 ulp), 1 = hardware v_sin/v_cos through the
+// fast-math intrinsics, 2 = own Cody-Waite + minimax polynomials (|x| <= 2 pi assumed).
+template <int TRIG>
+__device__ __forceinline__ void sincos_r(float x, float *s, float *c) {
+  if constexpr (TRIG == 0) {
+    sincosf(x, s, c);
+  } else if constexpr (TRIG == 1) {
+    *s = __sinf(x);
+    *c = __cosf(x);
+  } else {
+    float q = rintf(x * 0.636619746685028076f);           // x * 2/pi
+    float r = __builtin_fmaf(q, -1.57079625129699707f, x);  // pi/2 split hi
+    r = __builtin_fmaf(q, -7.54978941586159635e-08f, r);    // pi/2 split lo
+    int k = (int)q;
+    float r2 = r * r;
+    float ps = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, r2, -1.6666654611e-1f);
+    float sn = __builtin_fmaf(ps * r2, r, r);
+    float pc = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, r2, 4.166664568298827e-2f);
+    float cs = __builtin_fmaf(pc * r2, r2, __builtin_fmaf(r2, -0.5f, 1.0f));
+    float ss = (k & 1) ? cs : sn;
+    float cc = (k & 1) ? sn : cs;
+    *s = (k & 2) ? -ss : ss;
+    *c = ((k + 1) & 2) ? -cc : cc;
+  }
+}
+template <int TRIG>
+__device__ __forceinline__ void sincos_r(double x, double *s, double *c) {
+  sincos(x, s, c);
+}
+
+__device__ __forceinline__ float exp_r(float x) { return __expf(x); }
+__device__ __forceinline__ double exp_r(double x) { return exp(x); }
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return a * b + c; }
+
+template <typename R>
+__device__ __forceinline__ R u01(uint32_t w) {
+  return (R)(w >> 8) * (R)(1.0 / 16777216.0);
+}
+
+// dipole of one monomer: inc/dipole_response.jl:7-11 (dielectric), :27-29 with M = mu*I (polar)
+template <typename R, int CT>
+__device__ __forceinline__ void dipole(R a_or_mu, R k2e, R nx, R ny, R nz, R &mx, R &my, R &mz) {
+  if constexpr (CT == PSTAT_DIELECTRIC) {
+    R a = a_or_mu * nz;  // (K1-K2) E0 cos(theta)
+    mx = a * nx; my = a * ny; mz = a * nz + k2e;
+  } else {
+    mx = a_or_mu * nx; my = a_or_mu * ny; mz = a_or_mu * nz;
+  }
+}
+
+// one dipole-dipole term (inc/eap_chain.jl:200-207) for a bond vector r = x_i - x_j
+template <typename R>
+__device__ __forceinline__ R pair_term(R rx, R ry, R rz, R mix, R miy, R miz, R mjx, R mjy, R mjz) {
+  R r2 = rx * rx + ry * ry + rz * rz;
+  R rmag = sqrt(r2);
+  R hx = rx / rmag, hy = ry / rmag, hz = rz / rmag;
+  R r3 = r2 * rmag;
+  R mimj = mix * mjx + miy * mjy + miz * mjz;
+  R mir = mix * hx + miy * hy + miz * hz;
+  R mjr = mjx * hx + mjy * hy + mjz * hz;
+  return (mimj - 3 * mir * mjr) / ((R)(4.0 * 3.14159265358979323846) * r3);
+}
+
+// ------------------------------------------------------------------------------------------ init
+
+// EAPChain(pargs), inc/eap_chain.jl:60-135: all phi draws, then all theta draws; then r, p, U.
+// One thread per chain; angles are rounded to the storage type R before anything is derived.
+template <typename R>
+__global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
+                            int chain_type, int energy_type, double phi_step, double theta_step) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= S.C) return;
+  const int64_t icase = c / A.chains_per_case, local = c % A.chains_per_case;
+  const CaseConst cc = cases[icase];
+  R *th = (R *)S.ang, *ph = (R *)S.ang + A.n * S.C;
+  Xoshiro128pp g;
+  g.seed(cc.seed, cc.chain_id0 + (uint64_t)local);
+  for (int64_t i = 0; i < A.n; ++i) ph[i * S.C + c] = (R)(6.28318530717958647692 * u01<double>(g.next()));
+  for (int64_t i = 0; i < A.n; ++i) th[i * S.C + c] = (R)(3.14159265358979323846 * u01<double>(g.next()));
+
+  double r[3] = {0, 0, 0}, p[3] = {0, 0, 0}, usum = 0, upair = 0, omega = 0;
+  double pnx = 0, pny = 0, pnz = 0, pmx = 0, pmy = 0, pmz = 0;
+  for (int64_t i = 0; i < A.n; ++i) {
+    double t = (double)th[i * S.C + c], f = (double)ph[i * S.C + c];
+    double st = sin(t), ct = cos(t), sp = sin(f), cp = cos(f);
+    double nx = cp * st, ny = sp * st, nz = ct, mx, my, mz;
+    if (chain_type == PSTAT_DIELECTRIC)
+      dipole<double, PSTAT_DIELECTRIC>((cc.K1 - cc.K2) * cc.E0, cc.K2 * cc.E0, nx, ny, nz, mx, my, mz);
+    else
+      dipole<double, PSTAT_POLAR>(cc.mu, 0.0, nx, ny, nz, mx, my, mz);
+    r[0] += cc.b * nx; r[1] += cc.b * ny; r[2] += cc.b * nz;
+    p[0] += mx; p[1] += my; p[2] += mz;
+    usum += -0.5 * cc.E0 * mz;
+    omega += log(st);
+    if (energy_type == PSTAT_ISING && i > 0) {
+      double h = -cc.b / 2;
+      upair += pair_term<double>(h * (pnx + nx), h * (pny + ny), h * (pnz + nz), pmx, pmy, pmz, mx, my, mz);
+    }
+    pnx = nx; pny = ny; pnz = nz; pmx = mx; pmy = my; pmz = mz;
+  }
+  double U = usum + upair - (r[0] * cc.Fx + r[2] * cc.Fz);
+  S.obs[OBS_R1 * S.C + c] = r[0]; S.obs[OBS_R2 * S.C + c] = r[1]; S.obs[OBS_R3 * S.C + c] = r[2];
+  S.obs[OBS_P1 * S.C + c] = p[0]; S.obs[OBS_P2 * S.C + c] = p[1]; S.obs[OBS_P3 * S.C + c] = p[2];
+  S.obs[OBS_U * S.C + c] = U; S.obs[OBS_USUM * S.C + c] = usum;
+  S.rng[0 * S.C + c] = g.s0; S.rng[1 * S.C + c] = g.s1; S.rng[2 * S.C + c] = g.s2; S.rng[3 * S.C + c] = g.s3;
+  S.stepsz[0 * S.C + c] = phi_step; S.stepsz[1 * S.C + c] = theta_step;
+  S.win[0 * S.C + c] = 0; S.win[1 * S.C + c] = 0;
+  S.nacc_total[c] = 0;
+  for (int q = 0; q < NSUMS; ++q) S.sums[q * S.C + c] = 0.0;
+  S.wnorm[c] = 0.0;
+  S.lag[c] = 0.0;
+  (void)omega;
+}
+
+// ------------------------------------------------------------------------------------------ sweep
+
+template <typename R, int CT, int EN, bool FX, bool FLIPS, int TRIG>
+__global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
+                                                   const CaseConst *__restrict__ cases) {
+  using R2 = typename Vec2<R>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  R2 *ang = reinterpret_cast<R2 *>(smem);  // [n][lanes] : .x = theta, .y = phi
+
+  const int lane = threadIdx.x;
+  const int lanes = A.lanes;
+  const int64_t icase = blockIdx.x / A.blocks_per_case;
+  const int64_t local = (int64_t)(blockIdx.x % A.blocks_per_case) * lanes + lane;
+  // lanes own disjoint LDS columns and never exchange data, so idle lanes can simply leave
+  if (lane >= lanes || local >= A.chains_per_case) return;
+  const int64_t c = icase * A.chains_per_case + local;
+  const int64_t C = S.C;
+  const int n = (int)A.n;
+
+  // ---- per-case scalars (wave-uniform => SGPRs)
+  const CaseConst cc = cases[icase];
+  const R kT = (R)cc.kT, Fz = (R)cc.Fz, Fx = (R)cc.Fx, b = (R)cc.b;
+  (void)kT; (void)Fx;
+  const R a_or_mu = (CT == PSTAT_DIELECTRIC) ? (R)((cc.K1 - cc.K2) * cc.E0) : (R)cc.mu;
+  const R k2e = (R)(cc.K2 * cc.E0);
+  const R mhalfE0 = (R)(-0.5 * cc.E0);
+  const R invkT = (R)(1.0 / cc.kT);
+  (void)invkT;
+  const R hb = (R)(-cc.b / 2);
+  (void)hb;
+
+  // ---- fill: angles HBM -> LDS (coalesced over lanes), scalars HBM -> registers
+  {
+    const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
+    for (int i = 0; i < n; ++i) {
+      R2 v;
+      v.x = gth[(int64_t)i * C + c];
+      v.y = gph[(int64_t)i * C + c];
+      ang[i * lanes + lane] = v;
+    }
+  }
+  Xoshiro128pp g;
+  g.s0 = S.rng[0 * C + c]; g.s1 = S.rng[1 * C + c]; g.s2 = S.rng[2 * C + c]; g.s3 = S.rng[3 * C + c];
+  double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
+  R phistep = (R)phistep_d, thstep = (R)thstep_d;
+  int nacc = S.win[0 * C + c], natt = S.win[1 * C + c];
+  int nacc_seg = 0;
+  R rx = (R)S.obs[OBS_R1 * C + c], ry = (R)S.obs[OBS_R2 * C + c], rz = (R)S.obs[OBS_R3 * C + c];
+  R px = (R)S.obs[OBS_P1 * C + c], py = (R)S.obs[OBS_P2 * C + c], pz = (R)S.obs[OBS_P3 * C + c];
+  R U = (R)S.obs[OBS_U * C + c], usum = (R)S.obs[OBS_USUM * C + c];
+  R lag = (R)S.lag[c];
+  double sums[NSUMS];
+#pragma unroll
+  for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
+
+  int64_t step = A.step0;
+  int64_t remaining = A.nsteps;
+  const int64_t spa = A.steps_per_adjust;
+  constexpr int FLUSH = 128;  // f32 partial sums are folded into the f64 sums this often
+
+  while (remaining > 0) {
+    int64_t chunk = remaining < FLUSH ? remaining : FLUSH;
+    if (A.adaptive) {
+      int64_t to_adj = spa - (step % spa);
+      if (to_adj < chunk) chunk = to_adj;
+    }
+    R acc[NSUMS];
+#pragma unroll
+    for (int q = 0; q < NSUMS; ++q) acc[q] = 0;
+
+    for (int k = 0; k < (int)chunk; ++k) {
+      // ---- proposal, mcmc_eap_chain.jl:277-280
+      const uint32_t idx = __umulhi(g.next(), (uint32_t)n);
+      const R dphi = phistep * ((R)2 * u01<R>(g.next()) - (R)1);
+      const R2 a0 = ang[idx * lanes + lane];
+      const R th0 = a0.x, ph0 = a0.y;
+      R flip = 0;
+      if constexpr (FLIPS) {
+        if (g.next() >> 31) flip = K<R>::pi - 2 * th0;
+      }
+      const R dth = flip + thstep * ((R)2 * u01<R>(g.next()) - (R)1);
+      const R eps = u01<R>(g.next());
+
+      // ---- move!, inc/eap_chain.jl:232-245 (trial values only; committed on acceptance)
+      R ph1 = ph0 + dphi;
+      if constexpr (sizeof(R) == 4) {  // f32 only: keep |phi| small so its ulp stays ~2e-7
+        ph1 = ph1 >= K<R>::two_pi ? ph1 - K<R>::two_pi : ph1;
+        ph1 = ph1 < 0 ? ph1 + K<R>::two_pi : ph1;
+      }
+      const R th1 = fmin(K<R>::pi, fmax((R)0, th0 + dth));
+      R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
+      sincos_r<TRIG>(th0, &st0, &ct0);
+      sincos_r<TRIG>(ph0, &sp0, &cp0);
+      sincos_r<TRIG>(th1, &st1, &ct1);
+      sincos_r<TRIG>(ph1, &sp1, &cp1);
+      const R n0x = cp0 * st0, n0y = sp0 * st0, n0z = ct0;
+      const R n1x = cp1 * st1, n1y = sp1 * st1, n1z = ct1;
+      R m0x, m0y, m0z, m1x, m1y, m1z;
+      dipole<R, CT>(a_or_mu, k2e, n0x, n0y, n0z, m0x, m0y, m0z);
+      dipole<R, CT>(a_or_mu, k2e, n1x, n1y, n1z, m1x, m1y, m1z);
+
+      // ---- energy difference, inc/energy.jl:7-9,20-23; inc/eap_chain.jl:53
+      const R du = mhalfE0 * (m1z - m0z);
+      const R drx = b * (n1x - n0x), dry = b * (n1y - n0y), drz = b * (n1z - n0z);
+      R dpair = 0;
+      if constexpr (EN == PSTAT_ISING) {
+        R e0 = 0, e1 = 0;
+#pragma unroll
+        for (int side = -1; side <= 1; side += 2) {
+          const int j = (int)idx + side;
+          if (j >= 0 && j < n) {
+            const R2 aj = ang[j * lanes + lane];
+            R sj, cj, spj, cpj, mjx, mjy, mjz;
+            sincos_r<TRIG>(aj.x, &sj, &cj);
+            sincos_r<TRIG>(aj.y, &spj, &cpj);
+            const R njx = cpj * sj, njy = spj * sj, njz = cj;
+            dipole<R, CT>(a_or_mu, k2e, njx, njy, njz, mjx, mjy, mjz);
+            e0 += pair_term<R>(hb * (n0x + njx), hb * (n0y + njy), hb * (n0z + njz),
+                               m0x, m0y, m0z, mjx, mjy, mjz);
+            e1 += pair_term<R>(hb * (n1x + njx), hb * (n1y + njy), hb * (n1z + njz),
+                               m1x, m1y, m1z, mjx, mjy, mjz);
+          }
+        }
+        dpair = e1 - e0;
+      }
+      R dU;
+      if constexpr (FX) dU = du + dpair - (Fx * drx + Fz * drz);
+      else              dU = du + dpair - (Fz * drz);
+
+      // ---- Metropolis, inc/acceptance.jl:18-39.  pi ~ exp(-U/kT) * prod sin(theta)
+      bool ok;
+      if constexpr (sizeof(R) == 8) {
+        const R delta = -dU / kT + log(st1 / st0) - lag;
+        ok = (delta >= 0) || (eps < exp(delta));
+      } else {
+        // same test with the log folded away: eps < exp(-dU/kT) * sin(th1)/sin(th0)
+        ok = eps * st0 < st1 * exp_r(-dU * invkT - lag);
+      }
+      if (ok) {
+        R2 a1; a1.x = th1; a1.y = ph1;
+        ang[idx * lanes + lane] = a1;
+        rx += drx; ry += dry; rz += drz;
+        px += m1x - m0x; py += m1y - m0y; pz += m1z - m0z;
+        usum += du; U += dU;
+        lag = 0;
+        ++nacc; ++nacc_seg;
+      }
+      ++natt;
+
+      // ---- record! x 8, mcmc_eap_chain.jl:327-328 (every step, accepted or not)
+      acc[S_R1] += rx; acc[S_R2] += ry; acc[S_R3] += rz;
+      acc[S_R1SQ] = fma_r(rx, rx, acc[S_R1SQ]); acc[S_R2SQ] = fma_r(ry, ry, acc[S_R2SQ]);
+      acc[S_R3SQ] = fma_r(rz, rz, acc[S_R3SQ]);
+      acc[S_P1] += px; acc[S_P2] += py; acc[S_P3] += pz;
+      acc[S_P1SQ] = fma_r(px, px, acc[S_P1SQ]); acc[S_P2SQ] = fma_r(py, py, acc[S_P2SQ]);
+      acc[S_P3SQ] = fma_r(pz, pz, acc[S_P3SQ]);
+      acc[S_U] += U; acc[S_USQ] = fma_r(U, U, acc[S_USQ]);
+    }
+
+#pragma unroll
+    for (int q = 0; q < NSUMS; ++q) sums[q] += (double)acc[q];
+    step += chunk;
+    remaining -= chunk;
+
+    // ---- step-size adaptation, mcmc_eap_chain.jl:301-322 (per chain, in f64 like the reference)
+    if (A.adaptive && step % spa == 0) {
+      const double ratio = (double)nacc / (double)natt;
+      if (ratio > A.adj_ub && phistep_d != K<double>::pi && thstep_d != K<double>::half_pi) {
+        nacc = 0; natt = 0;
+        phistep_d = fmin(K<double>::pi, phistep_d * A.adj_scale);
+        thstep_d = fmin(K<double>::half_pi, thstep_d * A.adj_scale);
+      } else if (ratio < A.adj_lb) {
+        nacc = 0; natt = 0;
+        phistep_d /= A.adj_scale;
+        thstep_d /= A.adj_scale;
+      }
+      phistep = (R)phistep_d; thstep = (R)thstep_d;
+    }
+  }
+
+  // ---- spill
+  {
+    R *gth = (R *)S.ang, *gph = (R *)S.ang + (int64_t)n * C;
+    for (int i = 0; i < n; ++i) {
+      const R2 v = ang[i * lanes + lane];
+      gth[(int64_t)i * C + c] = v.x;
+      gph[(int64_t)i * C + c] = v.y;
+    }
+  }
+  S.rng[0 * C + c] = g.s0; S.rng[1 * C + c] = g.s1; S.rng[2 * C + c] = g.s2; S.rng[3 * C + c] = g.s3;
+  S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
+  S.win[0 * C + c] = nacc; S.win[1 * C + c] = natt;
+  S.nacc_total[c] += nacc_seg;
+  S.obs[OBS_R1 * C + c] = rx; S.obs[OBS_R2 * C + c] = ry; S.obs[OBS_R3 * C + c] = rz;
+  S.obs[OBS_P1 * C + c] = px; S.obs[OBS_P2 * C + c] = py; S.obs[OBS_P3 * C + c] = pz;
+  S.obs[OBS_U * C + c] = U; S.obs[OBS_USUM * C + c] = usum;
+  S.lag[c] = lag;
+#pragma unroll
+  for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
+}
+
+// ------------------------------------------------------------------------------------------ reduce
+
+constexpr int RED_BLOCKS = 256;
+constexpr int RED_THREADS = 256;
+constexpr int NQ = 17;  // 16 observables + acceptance ratio
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// stage 1: every block folds a strided slice of chains into partial[block][2*NQ] (deterministic)
+__global__ __launch_bounds__(RED_THREADS) void reduce_stage1(DevState S, int64_t c0, int64_t c1,
+                                                             int64_t steps, int umbrella,
+                                                             double *__restrict__ partial) {
+  __shared__ double red[RED_THREADS / 64][2 * NQ];
+  double m1[NQ], m2[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { m1[q] = 0; m2[q] = 0; }
+  const int64_t C = S.C;
+  for (int64_t c = c0 + (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; c < c1;
+       c += (int64_t)RED_BLOCKS * RED_THREADS) {
+    const double norm = umbrella ? S.wnorm[c] : (double)steps;
+    const double inv = norm != 0.0 ? 1.0 / norm : 0.0;
+    double v[NQ];
+    v[PSTAT_R1] = S.sums[S_R1 * C + c]; v[PSTAT_R2] = S.sums[S_R2 * C + c]; v[PSTAT_R3] = S.sums[S_R3 * C + c];
+    v[PSTAT_R1SQ] = S.sums[S_R1SQ * C + c]; v[PSTAT_R2SQ] = S.sums[S_R2SQ * C + c];
+    v[PSTAT_R3SQ] = S.sums[S_R3SQ * C + c];
+    v[PSTAT_RSQ] = v[PSTAT_R1SQ] + v[PSTAT_R2SQ] + v[PSTAT_R3SQ];
+    v[PSTAT_P1] = S.sums[S_P1 * C + c]; v[PSTAT_P2] = S.sums[S_P2 * C + c]; v[PSTAT_P3] = S.sums[S_P3 * C + c];
+    v[PSTAT_P1SQ] = S.sums[S_P1SQ * C + c]; v[PSTAT_P2SQ] = S.sums[S_P2SQ * C + c];
+    v[PSTAT_P3SQ] = S.sums[S_P3SQ * C + c];
+    v[PSTAT_PSQ] = v[PSTAT_P1SQ] + v[PSTAT_P2SQ] + v[PSTAT_P3SQ];
+    v[PSTAT_U] = S.sums[S_U * C + c]; v[PSTAT_USQ] = S.sums[S_USQ * C + c];
+#pragma unroll
+    for (int q = 0; q < PSTAT_NOBS; ++q) v[q] *= inv;
+    v[16] = steps > 0 ? (double)S.nacc_total[c] / (double)steps : 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { m1[q] += v[q]; m2[q] = fma(v[q], v[q], m2[q]); }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double a = wave_sum(m1[q]), b = wave_sum(m2[q]);
+    if (lane == 0) { red[wave][q] = a; red[wave][NQ + q] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * NQ) {
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < RED_THREADS / 64; ++w) t += red[w][threadIdx.x];
+    partial[blockIdx.x * 2 * NQ + threadIdx.x] = t;
+  }
+}
+
+// stage 2: one wave per output folds the RED_BLOCKS partials in a fixed order
+__global__ __launch_bounds__(64) void reduce_stage2(const double *__restrict__ partial,
+                                                    int64_t nchains, double *__restrict__ out) {
+  const int q = blockIdx.x;  // 0 .. 2*NQ-1
+  double t = 0;
+  for (int blk = threadIdx.x; blk < RED_BLOCKS; blk += 64) t += partial[blk * 2 * NQ + q];
+  t = wave_sum(t);
+  if (threadIdx.x == 0) {
+    out[1 + q] = t;
+    if (q == 0) out[0] = (double)nchains;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ re-init
+
+// mcmc_eap_chain.jl:352-361: draw a fresh configuration; adopt it if forced or by
+// metropolis_acc (inc/acceptance.jl:1-3).  One thread per chain.  The reference's acceptor keeps
+// the log-density it cached at the last acceptance, so after an adoption its comparisons are offset
+// by `lag` until the next accepted move -- reproduced here.
+template <typename R>
+__global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
+                              int chain_type, int energy_type, int force_init) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= S.C) return;
+  const int64_t C = S.C, n = A.n;
+  const CaseConst cc = cases[c / A.chains_per_case];
+  R *th = (R *)S.ang, *ph = (R *)S.ang + n * C;
+  R *nth = (R *)S.ang_tmp, *nph = (R *)S.ang_tmp + n * C;
+  Xoshiro128pp g;
+  g.s0 = S.rng[0 * C + c]; g.s1 = S.rng[1 * C + c]; g.s2 = S.rng[2 * C + c]; g.s3 = S.rng[3 * C + c];
+  for (int64_t i = 0; i < n; ++i) nph[i * C + c] = (R)(6.28318530717958647692 * u01<double>(g.next()));
+  for (int64_t i = 0; i < n; ++i) nth[i * C + c] = (R)(3.14159265358979323846 * u01<double>(g.next()));
+
+  double r[3] = {0, 0, 0}, p[3] = {0, 0, 0}, usum = 0, upair = 0, prod_new = 1.0, prod_old = 1.0;
+  double pnx = 0, pny = 0, pnz = 0, pmx = 0, pmy = 0, pmz = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    double t = (double)nth[i * C + c], f = (double)nph[i * C + c];
+    double st = sin(t), ct = cos(t), sp = sin(f), cp = cos(f);
+    double nx = cp * st, ny = sp * st, nz = ct, mx, my, mz;
+    if (chain_type == PSTAT_DIELECTRIC)
+      dipole<double, PSTAT_DIELECTRIC>((cc.K1 - cc.K2) * cc.E0, cc.K2 * cc.E0, nx, ny, nz, mx, my, mz);
+    else
+      dipole<double, PSTAT_POLAR>(cc.mu, 0.0, nx, ny, nz, mx, my, mz);
+    r[0] += cc.b * nx; r[1] += cc.b * ny; r[2] += cc.b * nz;
+    p[0] += mx; p[1] += my; p[2] += mz;
+    usum += -0.5 * cc.E0 * mz;
+    prod_new *= st;
+    prod_old *= sin((double)th[i * C + c]);
+    if (energy_type == PSTAT_ISING && i > 0) {
+      double h = -cc.b / 2;
+      upair += pair_term<double>(h * (pnx + nx), h * (pny + ny), h * (pnz + nz), pmx, pmy, pmz, mx, my, mz);
+    }
+    pnx = nx; pny = ny; pnz = nz; pmx = mx; pmy = my; pmz = mz;
+  }
+  const double U_new = usum + upair - (r[0] * cc.Fx + r[2] * cc.Fz);
+  const double U_old = S.obs[OBS_U * C + c];
+  bool adopt = force_init != 0;
+  if (!adopt) {
+    const double eps = u01<double>(g.next());
+    adopt = eps <= (exp(-(U_new - U_old) / cc.kT) * prod_new / prod_old);
+  }
+  if (adopt) {
+    const double lp_old = -U_old / cc.kT + log(prod_old);
+    const double lp_new = -U_new / cc.kT + log(prod_new);
+    S.lag[c] = (lp_old + S.lag[c]) - lp_new;
+    for (int64_t i = 0; i < n; ++i) { th[i * C + c] = nth[i * C + c]; ph[i * C + c] = nph[i * C + c]; }
+    S.obs[OBS_R1 * C + c] = r[0]; S.obs[OBS_R2 * C + c] = r[1]; S.obs[OBS_R3 * C + c] = r[2];
+    S.obs[OBS_P1 * C + c] = p[0]; S.obs[OBS_P2 * C + c] = p[1]; S.obs[OBS_P3 * C + c] = p[2];
+    S.obs[OBS_U * C + c] = U_new; S.obs[OBS_USUM * C + c] = usum;
+  }
+  S.rng[0 * C + c] = g.s0; S.rng[1 * C + c] = g.s1; S.rng[2 * C + c] = g.s2; S.rng[3 * C + c] = g.s3;
+}
+
+// ------------------------------------------------------------------------------------------ dispatch
+
+int choose_lanes(int precision, int64_t n, int energy_type) {
+  (void)energy_type;
+  const int64_t per_lane = n * (precision == PSTAT_F64 ? 16 : 8);
+  const int64_t budget = 160 * 1024;
+  for (int lanes = 64; lanes >= 8; lanes >>= 1)
+    if (per_lane * lanes <= budget) return lanes;
+  return 0;
+}
+
+using SweepFn = void (*)(SweepArgs, DevState, const CaseConst *);
+
+template <typename R, int CT, int EN, bool FX, bool FLIPS>
+static SweepFn pick_trig(int trig) {
+  if constexpr (sizeof(R) == 8) {
+    return sweep_kernel<R, CT, EN, FX, FLIPS, 0>;
+  } else {
+    switch (trig) {
+      case 1: return sweep_kernel<R, CT, EN, FX, FLIPS, 1>;
+      case 2: return sweep_kernel<R, CT, EN, FX, FLIPS, 2>;
+      default: return sweep_kernel<R, CT, EN, FX, FLIPS, 0>;
+    }
+  }
+}
+template <typename R, int CT, int EN>
+static SweepFn pick_flags(const LaunchCfg &cfg) {
+  if (cfg.has_fx) return cfg.do_flips ? pick_trig<R, CT, EN, true, true>(cfg.trig_mode)
+                                      : pick_trig<R, CT, EN, true, false>(cfg.trig_mode);
+  return cfg.do_flips ? pick_trig<R, CT, EN, false, true>(cfg.trig_mode)
+                      : pick_trig<R, CT, EN, false, false>(cfg.trig_mode);
+}
+template <typename R>
+static SweepFn pick_model(const LaunchCfg &cfg) {
+  const bool ising = cfg.energy_type == PSTAT_ISING;
+  if (cfg.chain_type == PSTAT_DIELECTRIC)
+    return ising ? pick_flags<R, PSTAT_DIELECTRIC, PSTAT_ISING>(cfg)
+                 : pick_flags<R, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING>(cfg);
+  return ising ? pick_flags<R, PSTAT_POLAR, PSTAT_ISING>(cfg)
+               : pick_flags<R, PSTAT_POLAR, PSTAT_NONINTERACTING>(cfg);
+}
+static SweepFn pick_sweep(const LaunchCfg &cfg) {
+  return cfg.precision == PSTAT_F64 ? pick_model<double>(cfg) : pick_model<float>(cfg);
+}
+
+static int sweep_lds_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
+  return (int)(a.n * a.lanes * (cfg.precision == PSTAT_F64 ? 16 : 8));
+}
+
+hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
+                             int *blocks_per_cu, const char **name) {
+  SweepFn fn = pick_sweep(cfg);
+  const int lds = sweep_lds_bytes(cfg, a);
+  hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  int nb = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fn, 64, lds);
+  if (e != hipSuccess) return e;
+  if (lds_bytes) *lds_bytes = lds;
+  if (blocks_per_cu) *blocks_per_cu = nb;
+  if (name) *name = cfg.precision == PSTAT_F64 ? "sweep_kernel<double>" : "sweep_kernel<float>";
+  return hipSuccess;
+}
+
+hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
+                        const CaseConst *cases, int ncases, hipStream_t stream) {
+  SweepFn fn = pick_sweep(cfg);
+  const int lds = sweep_lds_bytes(cfg, a);
+  hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)(a.blocks_per_case * ncases);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a, s, cases);
+  return hipGetLastError();
+}
+
+hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
+                       const CaseConst *cases, double phi_step, double theta_step,
+                       hipStream_t stream) {
+  const unsigned grid = (unsigned)((s.C + 255) / 256);
+  if (cfg.precision == PSTAT_F64)
+    hipLaunchKernelGGL(init_kernel<double>, dim3(grid), dim3(256), 0, stream, a, s, cases,
+                       cfg.chain_type, cfg.energy_type, phi_step, theta_step);
+  else
+    hipLaunchKernelGGL(init_kernel<float>, dim3(grid), dim3(256), 0, stream, a, s, cases,
+                       cfg.chain_type, cfg.energy_type, phi_step, theta_step);
+  return hipGetLastError();
+}
+
+hipError_t launch_reinit(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
+                         const CaseConst *cases, int force_init, hipStream_t stream) {
+  const unsigned grid = (unsigned)((s.C + 255) / 256);
+  if (cfg.precision == PSTAT_F64)
+    hipLaunchKernelGGL(reinit_kernel<double>, dim3(grid), dim3(256), 0, stream, a, s, cases,
+                       cfg.chain_type, cfg.energy_type, force_init);
+  else
+    hipLaunchKernelGGL(reinit_kernel<float>, dim3(grid), dim3(256), 0, stream, a, s, cases,
+                       cfg.chain_type, cfg.energy_type, force_init);
+  return hipGetLastError();
+}
+
+size_t reduce_scratch_doubles() { return (size_t)RED_BLOCKS * 2 * NQ; }
+
+hipError_t launch_reduce(const DevState &s, int64_t c0, int64_t c1, int64_t steps_recorded,
+                         int umbrella, double *partial, double *out, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_stage1, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream, s, c0, c1,
+                     steps_recorded, umbrella, partial);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(reduce_stage2, dim3(2 * NQ), dim3(64), 0, stream, partial, c1 - c0, out);
+  return hipGetLastError();
+}
+
+}  // namespace pstat

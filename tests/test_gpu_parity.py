@@ -1,0 +1,184 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Everything goes through the C ABI
+(libpstat.so via ctypes); the CPU oracle is only the checker.
+
+Tolerances:
+ * f64 kernel vs oracle, same stream: (theta, phi), generator state, acceptance counts and step
+   sizes BIT-EXACT (they depend only on additions, clamps and accept decisions); running sums to
+   1e-9 relative (device sin/cos/exp/log differ from glibc's in the last ulp).
+ * f32 kernel: statistical -- pooled ensemble means within 4 standard errors of the oracle's pooled
+   means (two-sample z), and of the f64 kernel's.
+"""
+import numpy as np
+import pytest
+
+from helpers import both, pooled
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ps():
+    import polymer_stats_amd as ps
+    assert ps._lib.load().pstat_device_count() >= 1, "no HIP device visible"
+    return ps
+
+
+def _bit_parity(ps, oracle, nsteps, nchains, **kw):
+    op, pp = both(nsteps, num_chains=nchains, precision=ps.F64, **kw)
+    with ps.Ensemble(pp) as e:
+        e.advance(nsteps)
+        e.sync()
+        for c in range(nchains):
+            o = oracle.run(op, chain_id=c, mode="fast", trace=True)
+            g = e.chain_state(c)
+            assert np.array_equal(g["theta"], o.final_theta), f"theta differs, chain {c}"
+            assert np.array_equal(g["phi"], o.final_phi), f"phi differs, chain {c}"
+            assert np.array_equal(g["rng"], o.rng), f"rng differs, chain {c}"
+            assert g["nacc_total"] == o.nacc_total
+            assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step
+            np.testing.assert_allclose(g["sums"], o.sums, rtol=1e-9, atol=1e-7)
+            np.testing.assert_allclose(e.microstate(c), np.r_[o.r, o.p, o.U], rtol=1e-9, atol=1e-9)
+
+
+def test_f64_bit_parity_config1(ps, oracle):
+    # BASELINE configs[0]: n=20, E0=0, Fz=1, kT=1 (adaptation active: 2500-step windows)
+    _bit_parity(ps, oracle, 12000, 70, n=20, E0=0.0, Fz=1.0, kT=1.0, seed=11)
+
+
+def test_f64_bit_parity_dielectric_fx_flips(ps, oracle):
+    _bit_parity(ps, oracle, 6000, 64, n=33, E0=1.5, K1=0.7, K2=0.3, Fz=0.4, Fx=0.3, kT=0.7, b=1.3,
+                do_flips=1, seed=5, steps_per_adjust=500)
+
+
+def test_f64_bit_parity_polar(ps, oracle):
+    _bit_parity(ps, oracle, 6000, 64, n=100, E0=1.0, mu=1.0, Fz=1.0, chain_type=1, seed=3)
+
+
+def test_f64_bit_parity_ising(ps, oracle):
+    _bit_parity(ps, oracle, 4000, 64, n=24, E0=1.0, K1=1.0, Fz=0.25, energy_type=2, seed=9,
+                steps_per_adjust=400)
+
+
+def test_f64_bit_parity_no_adaptation_single_monomer(ps, oracle):
+    _bit_parity(ps, oracle, 3000, 3, n=1, E0=2.0, K1=1.0, Fz=0.5, adj_scale=1.0, seed=2)
+
+
+def test_segments_checkpoint_and_sharding_invariance(ps, oracle):
+    """advance(a)+advance(b) == advance(a+b); checkpoint/restore resumes exactly; chains are
+    identified by global id, so a shard [32,64) of a 64-chain job reproduces those chains."""
+    op, pp = both(5000, num_chains=64, precision=ps.F32, n=40, E0=1.0, Fz=0.5, seed=21)
+    with ps.Ensemble(pp) as whole, ps.Ensemble(pp) as parts:
+        whole.advance(5000)
+        parts.advance(1234)
+        blob = parts.checkpoint()
+        parts.advance(777)           # diverge, then rewind
+        parts.restore(blob)
+        parts.advance(5000 - 1234)
+        a, b = whole.chain_state(17), parts.chain_state(17)
+        for k in ("theta", "phi", "rng"):
+            assert np.array_equal(a[k], b[k]), k
+        assert a["nacc_total"] == b["nacc_total"]
+        np.testing.assert_allclose(a["sums"], b["sums"], rtol=1e-5)
+    _, shard = both(5000, num_chains=32, chain_id0=32, precision=ps.F32, n=40, E0=1.0, Fz=0.5, seed=21)
+    with ps.Ensemble(pp) as whole, ps.Ensemble(shard) as half:
+        whole.advance(5000)
+        half.advance(5000)
+        a, b = whole.chain_state(32 + 5), half.chain_state(5)
+        assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["phi"], b["phi"])
+
+
+def test_batched_cases_match_single_case_handles(ps):
+    base = dict(num_chains=128, precision=ps.F32, n=30, E0=1.0, K1=1.0, seed=4)
+    cases = [ps.default_params(Fz=f, **base) for f in (0.0, 0.5, 2.0)]
+    with ps.Ensemble(cases) as batch:
+        batch.advance(3000)
+        for i, c in enumerate(cases):
+            with ps.Ensemble(c) as single:
+                single.advance(3000)
+                a, b = batch.chain_state(i * 128 + 7), single.chain_state(7)
+                assert np.array_equal(a["theta"], b["theta"])
+                avg_b, _ = batch.rolling(i)
+                avg_s, _ = single.rolling(-1)
+                np.testing.assert_allclose(avg_b, avg_s, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("trig", ["0", "1", "2"])
+def test_f32_statistical_parity_config2(ps, oracle, golden, trig, monkeypatch):
+    """BASELINE configs[1] at Fz=1: n=100 dielectric.  f32 kernel vs CPU oracle under the SAME
+    protocol (no burn-in, adaptation on): pooled means agree within 4 sigma."""
+    monkeypatch.setenv("PSTAT_TRIG", trig)
+    nsteps, nch = 20000, 4096
+    op, pp = both(nsteps, num_chains=nch, precision=ps.F32, n=100, E0=1.0, K1=1.0, K2=0.0, Fz=1.0, seed=77)
+    with ps.Ensemble(pp) as e:
+        e.advance(nsteps)
+        g_avg, g_se = e.rolling()
+        s = e.summary()
+    osums, onorm, onacc = oracle.run_many(op, 10_000_000, 256, nthreads=8, mode="fast")
+    o_avg, o_se = pooled(osums, onorm)
+    z = (g_avg - o_avg) / np.sqrt(g_se ** 2 + o_se ** 2 + 1e-300)
+    assert np.all(np.abs(z) < 4.0), dict(zip(ps.OBS_NAMES, np.round(z, 2)))
+    assert abs(s.acceptance_ratio - onacc.mean() / nsteps) < 4 * (s.ar_stderr + onacc.std() / nsteps / 16)
+    # sanity against equilibrium with the no-burn-in transient allowed for (tau ~ 10 n steps)
+    eq = golden["cfg2_n100_E0_1_K1_1_Fz1"]["avg"]
+    assert abs(g_avg[2] - eq["r3"]) < 0.06 * eq["r3"]
+    assert abs(g_avg[9] - eq["p3"]) < 0.06 * eq["p3"]
+
+
+def test_f32_vs_f64_same_seeds(ps):
+    """Same seeds => same proposals, so the two precisions differ by arithmetic only."""
+    nsteps, nch = 20000, 1024
+    out = {}
+    for prec in (ps.F32, ps.F64):
+        pp = ps.default_params(num_chains=nch, precision=prec, n=64, E0=1.0, K1=1.0, Fz=0.5, seed=5)
+        with ps.Ensemble(pp) as e:
+            e.advance(nsteps)
+            out[prec] = e.rolling()
+    (a32, s32), (a64, s64) = out[ps.F32], out[ps.F64]
+    z = (a32 - a64) / np.sqrt(s32 ** 2 + s64 ** 2 + 1e-300)
+    assert np.all(np.abs(z) < 4.0), z
+
+
+def test_long_run_matches_closed_form_config3(ps, golden):
+    """BASELINE configs[2] point (polar, E0=1, mu=1, Fz=1): with N >> tau the protocol's transient
+    bias is below the pooled standard error budgeted here."""
+    nsteps, nch = 200000, 2048
+    pp = ps.default_params(num_chains=nch, precision=ps.F32, n=100, E0=1.0, mu=1.0, Fz=1.0,
+                           chain_type=ps.POLAR, seed=123)
+    with ps.Ensemble(pp) as e:
+        e.advance(nsteps)
+        avg, se = e.rolling()
+    eq = golden["cfg3_polar_n100_E0_1_mu1_Fz1"]["avg"]
+    # transient: (tau/N)(r_eq - r_0) with tau ~ 10 n = 1000 steps -> ~0.5% of r_eq
+    assert abs(avg[2] - eq["r3"]) < 0.01 * eq["r3"] + 4 * se[2]
+    assert abs(avg[9] - eq["p3"]) < 0.01 * eq["p3"] + 4 * se[9]
+    assert abs(avg[14] - eq["U"]) < 0.01 * abs(eq["U"]) + 4 * se[14]
+
+
+def test_reinit_force_and_metropolis(ps, oracle):
+    """--num-inits 3: f64 kernel vs oracle fast mode, including the acceptor's stale cache."""
+    for force in (1, 0):
+        nsteps, inits = 1500, 3
+        op, pp = both(nsteps, num_chains=64, precision=ps.F64, num_inits=inits, force_init=force,
+                      n=12, E0=1.0, K1=1.0, Fz=0.3, seed=31, steps_per_adjust=500)
+        with ps.Ensemble(pp) as e:
+            for k in range(inits):
+                e.advance(nsteps)
+                if k + 1 < inits:
+                    e.reinit(bool(force))
+            for c in (0, 13, 63):
+                o = oracle.run(op, chain_id=c, mode="fast", trace=True)
+                g = e.chain_state(c)
+                assert np.array_equal(g["theta"], o.final_theta), (force, c)
+                assert np.array_equal(g["rng"], o.rng)
+                assert g["nacc_total"] == o.nacc_total
+                np.testing.assert_allclose(g["sums"], o.sums, rtol=1e-9, atol=1e-7)
+
+
+def test_errors_are_loud(ps):
+    with pytest.raises(ps.PstatError):
+        ps.Ensemble(ps.default_params(n=0))
+    with pytest.raises(ps.PstatError):
+        ps.Ensemble(ps.default_params(kT=0.0))
+    with pytest.raises(ps.PstatError) as ei:
+        ps.Ensemble(ps.default_params(energy_type=ps.INTERACTING))
+    assert ei.value.code == -4

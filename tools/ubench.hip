@@ -1,0 +1,115 @@
+// ubench.hip -- instruction-rate and trig-accuracy microbenchmarks that size the sweep kernel's
+// design choices on gfx950.  Build: hipcc -O3 --offload-arch=gfx950 tools/ubench.hip -o tools/ubench
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+constexpr int ITERS = 4096;
+constexpr int ACC = 8;
+
+enum Op { FMA32, MULLO, MULHI, SIN, EXP2, RCP, FMA64, ADD64, XORSHIFT, CVT, PKFMA, LDSB64 };
+
+template <int OP>
+__global__ __launch_bounds__(64) void rate_kernel(float *out, int nrows) {
+  extern __shared__ float2 lds[];
+  float a[ACC]; uint32_t u[ACC]; double d[ACC];
+  for (int i = 0; i < ACC; ++i) { a[i] = 0.001f * (threadIdx.x + i + 1); u[i] = threadIdx.x * 2654435761u + i; d[i] = a[i]; }
+  if (OP == LDSB64) for (int r = 0; r < nrows; ++r) lds[r * 64 + threadIdx.x] = make_float2(r, threadIdx.x);
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) {
+      if (OP == FMA32) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
+      if (OP == MULLO) u[i] = u[i] * 0xD2511F53u + 1u;
+      if (OP == MULHI) u[i] = __umulhi(u[i], 0xCD9E8D57u) + 12345u;
+      if (OP == SIN) a[i] = __builtin_amdgcn_sinf(a[i]);
+      if (OP == EXP2) a[i] = __builtin_amdgcn_exp2f(a[i]);
+      if (OP == RCP) a[i] = __builtin_amdgcn_rcpf(a[i]);
+      if (OP == FMA64) d[i] = d[i] * 1.0000001 + 0.5;
+      if (OP == ADD64) d[i] = d[i] + 0.5;
+      if (OP == XORSHIFT) u[i] = (u[i] ^ (u[i] << 9)) + __builtin_rotateleft32(u[i], 7);
+      if (OP == CVT) a[i] += (float)(u[i] >> 8), u[i] += 77u;
+      if (OP == PKFMA) {
+        typedef float v2 __attribute__((ext_vector_type(2)));
+        v2 x = {a[i], a[(i + 1) % ACC]};
+        x = __builtin_elementwise_fma(x, (v2){1.0001f, 1.0002f}, (v2){0.5f, 0.25f});
+        a[i] = x.x;
+      }
+      if (OP == LDSB64) {
+        uint32_t row = __umulhi(u[i], (uint32_t)nrows);
+        float2 v = lds[row * 64 + threadIdx.x];
+        u[i] = u[i] * 1664525u + 1013904223u + (uint32_t)v.x;
+      }
+    }
+  }
+  float s = 0; for (int i = 0; i < ACC; ++i) s += a[i] + (float)u[i] + (float)d[i];
+  if (s == 123.456f) out[0] = s;
+}
+
+template <int OP>
+int run(const char *name, int waves_per_cu, int nrows = 0) {
+  float *out; CHECK(hipMalloc(&out, 4));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  int grid = 256 * waves_per_cu;
+  size_t lds = OP == LDSB64 ? (size_t)nrows * 64 * 8 : 0;
+  if (lds) CHECK(hipFuncSetAttribute((const void *)rate_kernel<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(rate_kernel<OP>, dim3(grid), dim3(64), lds, 0, out, nrows);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(rate_kernel<OP>, dim3(grid), dim3(64), lds, 0, out, nrows);
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+  double instr_per_wave = (double)ITERS * ACC;
+  double ns_per_instr = ms * 1e6 / instr_per_wave;            // per wave-instruction, as seen by one wave
+  // waves per SIMD = waves_per_cu / 4 (dispatcher spreads 1-wave groups over SIMDs)
+  double per_simd = ns_per_instr / ((waves_per_cu + 3) / 4);
+  printf("%-10s waves/CU=%2d  %8.3f ms   %.3f ns per wave-instr per wave  (%.2f cyc @2.4GHz; per-SIMD issue interval %.2f cyc)\n",
+         name, waves_per_cu, ms, ns_per_instr, ns_per_instr * 2.4, per_simd * 2.4);
+  CHECK(hipFree(out));
+  return 0;
+}
+
+__global__ void trig_err_kernel(int n, double *maxerr) {
+  // max abs error over x in [0, 2pi): [0]=__sinf [1]=__cosf [2]=v_sin(turns) [3]=sincosf(sin) [4]=__expf rel on [-20,5]
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double x = 6.283185307179586 * (i + 0.5) / n;
+  float xf = (float)x;
+  double xs = (double)xf;
+  double e0 = fabs((double)__sinf(xf) - sin(xs));
+  double e1 = fabs((double)__cosf(xf) - cos(xs));
+  float turns = (float)((i + 0.5) / n);
+  double e2 = fabs((double)__builtin_amdgcn_sinf(turns) - sin(6.283185307179586 * (double)turns));
+  float s, c; sincosf(xf, &s, &c);
+  double e3 = fabs((double)s - sin(xs));
+  float y = -20.0f + 25.0f * (float)((i + 0.5) / n);
+  double e4 = fabs((double)__expf(y) / exp((double)y) - 1.0);
+  double e[5] = {e0, e1, e2, e3, e4};
+  for (int k = 0; k < 5; ++k) {
+    unsigned long long *p = (unsigned long long *)&maxerr[k];
+    unsigned long long v = __double_as_longlong(e[k]);
+    atomicMax(p, v);  // non-negative doubles order like their bit patterns
+  }
+}
+
+int main() {
+  hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s  CUs=%d  clock=%d kHz  LDS/CU=%zu\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate, prop.maxSharedMemoryPerMultiProcessor);
+  for (int w : {4, 8, 16}) {
+    run<FMA32>("fma_f32", w); run<MULLO>("mul_lo_u32", w); run<MULHI>("mul_hi_u32", w);
+    run<SIN>("v_sin_f32", w); run<EXP2>("v_exp_f32", w); run<RCP>("v_rcp_f32", w);
+    run<FMA64>("fma_f64", w); run<ADD64>("add_f64", w); run<XORSHIFT>("xor/shl/rot", w);
+    run<CVT>("cvt+add", w); run<PKFMA>("pk_fma_f32", w);
+  }
+  for (int w : {1, 2, 3}) run<LDSB64>("lds_b64_rand", w, 100);
+  run<LDSB64>("lds_b64_rand", 8, 30);
+  double *d; CHECK(hipMalloc(&d, 5 * 8)); CHECK(hipMemset(d, 0, 5 * 8));
+  int n = 1 << 22;
+  hipLaunchKernelGGL(trig_err_kernel, dim3(n / 256), dim3(256), 0, 0, n, d);
+  double h[5]; CHECK(hipMemcpy(h, d, 5 * 8, hipMemcpyDeviceToHost));
+  printf("max abs err on [0,2pi): __sinf %.3e  __cosf %.3e  v_sin(turns) %.3e  sincosf %.3e ; __expf max rel err on [-20,5] %.3e\n", h[0], h[1], h[2], h[3], h[4]);
+  return 0;
+}
