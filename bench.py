@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the fixed-force MCMC hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): non-interacting dielectric chain, n = 100, E0 = 1, K1 = 1,
+K2 = 0, kT = 1, b = 1, one point of the Fz sweep per bench step, 65 536 chains per GPU, 1e5 MC steps
+per chain (6.55e9 attempted monomer updates per GPU per step).  Weak scaling: every rank runs its own
+65 536 chains (global chain ids rank*65536 ...), no data-path collective; the only exchange is one
+RCCL all-reduce of the 35-double reduction vector per step.
+
+A bench "step" = advance every chain of one Fz point by --mc-steps Monte-Carlo steps (ONE launch of
+the sweep kernel) + the on-device reduction + the all-reduce.  Chain states are created (on the
+device) before the timed region, so inputs are resident in HBM when it starts.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (16 B per attempted update
+in f32: one (theta, phi) pair read and written; 32 B in f64 -- SURVEY.md 8(d)) x updates per launch /
+mean launch time measured with HIP events on the launch stream.  The path is bound by VALU issue,
+not by HBM (state lives in LDS/registers); the extra `valu` object prices it against that ceiling.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FZ_SWEEP = [round(0.05 * i, 2) for i in range(21)] + [1.5 + 0.5 * i for i in range(8)]  # run/noninteracting-compare-*.jl:21
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz = 7.86e13 lane-ops/s
+VALU_OPS_PER_UPDATE = 220      # ~100 flop + 7 transcendentals + ~110 int per update
+
+
+def cpu_baseline(n, mc_steps, target_seconds=15.0):
+    """Times the CPU restatement of the reference algorithm (oracle, faithful mode: deep copy +
+    full recompute per step, fp64) on this host: one single-threaded chain per worker thread over all
+    cores, like the reference's pmap farm.  Bounded sample of the same workload."""
+    from oracle import binding as ob
+    cores = os.cpu_count() or 1
+    P = ob.make_params(n=n, E0=1.0, K1=1.0, K2=0.0, kT=1.0, Fz=1.0, b=1.0, num_steps=mc_steps, seed=1, stepout=0)
+    t0 = time.perf_counter()
+    ob.run(P, chain_id=0, mode="faithful")
+    one = max(time.perf_counter() - t0, 1e-4)
+    per_thread = max(1, int(target_seconds / one))
+    nchains = cores * per_thread
+    t0 = time.perf_counter()
+    ob.run_many(P, id0=1, nchains=nchains, nthreads=cores, mode="faithful")
+    wall = time.perf_counter() - t0
+    return {"value": nchains * mc_steps / wall, "unit": "MC monomer-updates/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{nchains} chains x {mc_steps} steps, n={n}, Fz=1, oracle faithful mode (deep copy + "
+                      f"full recompute per step, fp64, one thread per chain), {wall:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--mc-steps", type=int, default=100000, help="MC steps per chain per bench step")
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import polymer_stats_amd as ps
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libpstat has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    prec = ps.F64 if args.precision == "f64" else ps.F32
+    stream = torch.cuda.Stream()
+    nstep_total = args.steps + args.warmup
+    red = torch.zeros(ps.NRED, dtype=torch.float64, device="cuda")
+    with torch.cuda.stream(stream):
+        # one ensemble per bench step (a point of the Fz sweep), initialised on the device up front
+        ens = []
+        for i in range(nstep_total):
+            p = ps.default_params(n=args.n, E0=1.0, K1=1.0, K2=0.0, kT=1.0, b=1.0, Fz=FZ_SWEEP[i % len(FZ_SWEEP)],
+                                  num_chains=args.chains, chain_id0=rank * args.chains,
+                                  seed=20260501 + i, precision=prec, device=local_rank)
+            ens.append(ps.Ensemble(p, stream=stream.cuda_stream))
+        info = ens[0].launch_info()
+
+        def one_step(e, ev=None):
+            if ev:
+                ev[0].record(stream)
+            e.advance(args.mc_steps)
+            if ev:
+                ev[1].record(stream)
+            e.reduce_into(red.data_ptr())
+            if world > 1:
+                dist.all_reduce(red)
+
+        for i in range(args.warmup):
+            one_step(ens[i])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(ens[args.warmup + i], events[i])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    last = ps.summary_from_reduction(red.cpu().tolist(), args.mc_steps)
+
+    if rank == 0:
+        upd_per_launch = args.chains * args.mc_steps
+        total_updates = world * upd_per_launch * args.steps
+        value = total_updates / elapsed
+        mean_ms = sum(kernel_ms) / len(kernel_ms)
+        bytes_per_update = 32 if prec == ps.F64 else 16
+        achieved = bytes_per_update * upd_per_launch / (mean_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                key = f"{args.precision}_n{args.n}_c{args.chains}_s{args.mc_steps}"
+                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        upd_rate_kernel = upd_per_launch / (mean_ms * 1e-3)
+        out = {
+            "metric": "MC monomer-updates/sec (whole node) at n=100",
+            "value": value, "unit": "MC monomer-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 state+transcendentals, f64 running sums" if prec == ps.F32 else "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: non-interacting dielectric chain, n=%d, E0=1, K1=1, K2=0, "
+                                   "kT=1, b=1, Fz sweep (one point per step), %d chains/GPU x %d MC steps"
+                                   % (args.n, args.chains, args.mc_steps),
+                       "chains_per_gpu": args.chains, "mc_steps_per_chain": args.mc_steps, "n": args.n,
+                       "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-reduce of {ps.NRED} doubles per step",
+                       "kernel": info.kernel.decode(), "lds_bytes_per_wg": info.lds_bytes,
+                       "workgroups": int(info.blocks), "wg_per_cu_resident": info.blocks_per_cu},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": mean_ms,
+                         "note": "algorithmic bytes = %d B/update x %d updates per launch; the kernel keeps state in "
+                                 "LDS/registers, so HBM is not what bounds it -- see 'valu'" % (bytes_per_update, upd_per_launch)},
+            "valu": {"bound": "valu-issue", "achieved": upd_rate_kernel * VALU_OPS_PER_UPDATE / 1e12,
+                     "peak": VALU_LANE_OPS_PEAK / 1e12, "unit": "T lane-ops/s",
+                     "frac": upd_rate_kernel * VALU_OPS_PER_UPDATE / VALU_LANE_OPS_PEAK,
+                     "ops_per_update": VALU_OPS_PER_UPDATE},
+            "check": {"Fz": FZ_SWEEP[(nstep_total - 1) % len(FZ_SWEEP)], "r3": last.avg[2], "r3_stderr": last.stderr[2],
+                      "p3": last.avg[9], "U": last.avg[14], "AR": last.acceptance_ratio,
+                      "chains_pooled": int(last.num_chains)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.n, args.mc_steps)
+        print(json.dumps(out), flush=True)
+    for e in ens:
+        e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,7 @@
  *
  * Random stream contract (ours; the reference is unseeded, mcmc_eap_chain.jl has no seed):
  *   state   = xoshiro128++ seeded with Philox4x32-10(key = seed, ctr = (chain_lo, chain_hi, 0x5eed, 0))
- *   u(w)    = (w >> 8) * 2^-24
+ *   u(w)    = (w >> 9) * 2^-23   (23 bits: exactly the f32 mantissa trick the kernels use)
  *   init    : phi_i = 2pi*u  for i = 1..n, then theta_i = pi*u for i = 1..n   (eap_chain.jl:6-7,61-62)
  *   step    : idx = mulhi32(w, n); dphi = phi_step*(2u-1); [flip bit = w>>31 if --do-flips];
  *             dtheta = theta_step*(2u-1); eps = u                              (mcmc_eap_chain.jl:277-287)
@@ -71,7 +71,7 @@ uint32_t eap_xoshiro128pp_next(uint32_t s[4]) {
   return result;
 }
 
-double eap_u01(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
+double eap_u01(uint32_t w) { return (double)(w >> 9) * (1.0 / 8388608.0); }
 
 static inline double draw_u(uint32_t s[4]) { return eap_u01(eap_xoshiro128pp_next(s)); }
 static inline int64_t draw_idx(uint32_t s[4], int64_t n) {

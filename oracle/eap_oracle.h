@@ -78,7 +78,7 @@ typedef struct eap_trace {
 void eap_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void eap_rng_seed(uint64_t seed, uint64_t chain_id, uint32_t s[4]);
 uint32_t eap_xoshiro128pp_next(uint32_t s[4]);
-double eap_u01(uint32_t w);                       /* (w>>8) * 2^-24 in [0,1) */
+double eap_u01(uint32_t w);                       /* (w>>9) * 2^-23 in [0,1) */
 
 /* --- the two restatements --- */
 /* Literal algorithm: trial = deep copy, full prefix sum, full energy recompute,

@@ -52,7 +52,7 @@ struct SweepArgs {
 // ---------------------------------------------------------------------------------------------
 // Random stream contract (restated, not shared, in oracle/eap_oracle.c):
 //   xoshiro128++ seeded by Philox4x32-10(key = seed, ctr = (chain_lo, chain_hi, 0x5eed, 0));
-//   u(w) = (w >> 8) * 2^-24;  idx = mulhi32(w, n).
+//   u(w) = (w >> 9) * 2^-23;  idx = mulhi32(w, n).
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {

@@ -83,9 +83,18 @@ __device__ __forceinline__ double exp_r(double x) { return exp(x); }
 __device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_r(double a, double b, double c) { return a * b + c; }
 
+// u(w) = (w >> 9) * 2^-23 in [0,1).  v_cvt_f32_u32 is a quarter-rate instruction on gfx950, so the
+// f32 forms splice the 23 bits into the mantissa of a float in [1,2) (or [2,4) for 2u-1) instead:
+// two full-rate integer ops and one add, and the result is exactly the same number.
 template <typename R>
 __device__ __forceinline__ R u01(uint32_t w) {
-  return (R)(w >> 8) * (R)(1.0 / 16777216.0);
+  if constexpr (sizeof(R) == 4) return __uint_as_float(0x3F800000u | (w >> 9)) - 1.0f;
+  else return (R)(w >> 9) * (R)(1.0 / 8388608.0);
+}
+template <typename R>
+__device__ __forceinline__ R sym11(uint32_t w) {  // 2u - 1 in [-1,1)
+  if constexpr (sizeof(R) == 4) return __uint_as_float(0x40000000u | (w >> 9)) - 3.0f;
+  else return (R)2 * ((R)(w >> 9) * (R)(1.0 / 8388608.0)) - (R)1;
 }
 
 // dipole of one monomer: inc/dipole_response.jl:7-11 (dielectric), :27-29 with M = mu*I (polar)
@@ -236,14 +245,14 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
     for (int k = 0; k < (int)chunk; ++k) {
       // ---- proposal, mcmc_eap_chain.jl:277-280
       const uint32_t idx = __umulhi(g.next(), (uint32_t)n);
-      const R dphi = phistep * ((R)2 * u01<R>(g.next()) - (R)1);
+      const R dphi = phistep * sym11<R>(g.next());
       const R2 a0 = ang[idx * lanes + lane];
       const R th0 = a0.x, ph0 = a0.y;
       R flip = 0;
       if constexpr (FLIPS) {
         if (g.next() >> 31) flip = K<R>::pi - 2 * th0;
       }
-      const R dth = flip + thstep * ((R)2 * u01<R>(g.next()) - (R)1);
+      const R dth = flip + thstep * sym11<R>(g.next());
       const R eps = u01<R>(g.next());
 
       // ---- move!, inc/eap_chain.jl:232-245 (trial values only; committed on acceptance)

