@@ -36,18 +36,45 @@ VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz = 7.8
 VALU_OPS_PER_UPDATE = 220      # ~100 flop + 7 transcendentals + ~110 int per update
 
 
-def cpu_baseline(n, mc_steps, target_seconds=15.0):
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            if parse:
+                q, per = parse(open(path).read())
+            else:
+                q = open(path).read().strip()
+                per = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if q not in ("max", "-1"):
+                n = min(n, max(1, int(float(q) / float(per))))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(n, mc_steps, target_seconds=12.0):
     """Times the CPU restatement of the reference algorithm (oracle, faithful mode: deep copy +
     full recompute per step, fp64) on this host: one single-threaded chain per worker thread over all
     cores, like the reference's pmap farm.  Bounded sample of the same workload."""
     from oracle import binding as ob
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     P = ob.make_params(n=n, E0=1.0, K1=1.0, K2=0.0, kT=1.0, Fz=1.0, b=1.0, num_steps=mc_steps, seed=1, stepout=0)
     t0 = time.perf_counter()
     ob.run(P, chain_id=0, mode="faithful")
     one = max(time.perf_counter() - t0, 1e-4)
-    per_thread = max(1, int(target_seconds / one))
+    per_thread = max(1, min(1024, int(target_seconds / one)))
     nchains = cores * per_thread
+    log(f"cpu baseline: {cores} threads x {per_thread} chains, one chain takes {one:.3f} s")
     t0 = time.perf_counter()
     ob.run_many(P, id0=1, nchains=nchains, nthreads=cores, mode="faithful")
     wall = time.perf_counter() - t0
@@ -98,6 +125,8 @@ def main():
                                   seed=20260501 + i, precision=prec, device=local_rank)
             ens.append(ps.Ensemble(p, stream=stream.cuda_stream))
         info = ens[0].launch_info()
+        log(f"rank {rank}: {nstep_total} ensembles ready; kernel {info.kernel.decode()} lds={info.lds_bytes} "
+            f"wgs={info.blocks} wg/cu={info.blocks_per_cu}")
 
         def one_step(e, ev=None):
             if ev:
@@ -110,7 +139,10 @@ def main():
                 dist.all_reduce(red)
 
         for i in range(args.warmup):
+            tw = time.perf_counter()
             one_step(ens[i])
+            torch.cuda.synchronize()
+            log(f"rank {rank}: warmup step {i} took {time.perf_counter() - tw:.3f} s")
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -125,6 +157,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        log(f"rank {rank}: {args.steps} timed steps in {elapsed:.3f} s")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
