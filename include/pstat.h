@@ -130,6 +130,9 @@ int pstat_reinit(pstat_handle *h, int32_t force_init);
  * `dev_out`, a DEVICE pointer to PSTAT_NRED doubles owned by the caller (e.g. a torch tensor that
  * is then all-reduced with RCCL).  Asynchronous on the handle's stream. */
 int pstat_reduce_device(pstat_handle *h, int32_t icase, double *dev_out);
+/* The same vector copied back to host memory (synchronises): shards held by several handles in one
+ * process (one per device) are merged by adding their vectors. */
+int pstat_reduce_host(pstat_handle *h, int32_t icase, double red_out[PSTAT_NRED]);
 
 /* Replaces get_avg() over the 8 averagers as written to rolling.csv (mcmc_eap_chain.jl:334-346;
  * inc/average.jl:38): pooled running averages of case `icase`, plus across-chain standard errors.

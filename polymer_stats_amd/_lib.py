@@ -20,7 +20,7 @@ OBS_NAMES = ["r1", "r2", "r3", "r1sq", "r2sq", "r3sq", "rsq",
 SYMBOLS = [
     "pstat_abi_version", "pstat_strerror", "pstat_last_error", "pstat_device_count",
     "pstat_default_params", "pstat_create", "pstat_destroy", "pstat_advance", "pstat_sync",
-    "pstat_reinit", "pstat_reduce_device", "pstat_rolling", "pstat_microstate",
+    "pstat_reinit", "pstat_reduce_device", "pstat_reduce_host", "pstat_rolling", "pstat_microstate",
     "pstat_summary_get", "pstat_summary_from_reduction", "pstat_chain_state",
     "pstat_checkpoint", "pstat_restore", "pstat_launch_info_get",
 ]
@@ -82,6 +82,7 @@ def load():
     L.pstat_sync.argtypes = [vp]
     L.pstat_reinit.argtypes = [vp, i32]
     L.pstat_reduce_device.argtypes = [vp, i32, vp]
+    L.pstat_reduce_host.argtypes = [vp, i32, dp]
     L.pstat_rolling.argtypes = [vp, i32, dp, dp]
     L.pstat_microstate.argtypes = [vp, i64, dp]
     L.pstat_summary_get.argtypes = [vp, i32, C.POINTER(Summary)]

@@ -325,6 +325,11 @@ int pstat_reduce_device(pstat_handle *h, int32_t icase, double *dev_out) {
   return PSTAT_OK;
 }
 
+int pstat_reduce_host(pstat_handle *h, int32_t icase, double red_out[PSTAT_NRED]) {
+  if (!h || !red_out) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  return reduce_to_host(h, icase, red_out);
+}
+
 int pstat_summary_from_reduction(const double red[PSTAT_NRED], int64_t steps_per_chain,
                                  pstat_summary *out) {
   if (!red || !out) return fail(PSTAT_ERR_INVALID_ARG, "null argument");

@@ -59,6 +59,11 @@ class Ensemble:
         """Device-side reduction into a caller-owned device buffer of NRED doubles (async)."""
         check(self._L.pstat_reduce_device(self._h, icase, C.c_void_p(dev_ptr)))
 
+    def reduce_host(self, icase: int = -1) -> np.ndarray:
+        red = np.zeros(NRED)
+        check(self._L.pstat_reduce_host(self._h, icase, red.ctypes.data_as(C.POINTER(C.c_double))))
+        return red
+
     def summary(self, icase: int = -1) -> Summary:
         s = Summary()
         check(self._L.pstat_summary_get(self._h, icase, C.byref(s)))

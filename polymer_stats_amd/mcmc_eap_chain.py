@@ -1,0 +1,264 @@
+"""Host side of the drop-in: the command line, `mcmc(nsteps, pargs)` and the three outputs of the
+reference's mcmc_eap_chain.jl, with the step loop running on the GPU through libpstat (C ABI).
+
+    python -m polymer_stats_amd.mcmc_eap_chain --chain-type dielectric -n 100 -e 1 -F 1 -N 100000 \
+           --num-chains 65536 --prefix out/run1 -v 2
+
+Same option names, short aliases, types and defaults as mcmc_eap_chain.jl:19-153; same files
+(<prefix>_trajectory.csv, <prefix>_rolling.csv: :256-259,329-348) and the same ten stdout lines
+(:386-395).  Options added by this implementation: --num-chains, --seed, --devices, --precision.
+`--num-chains C` runs C independent chains, each statistically one reference run with the given
+options, and pools them; everything the reference prints is then the pooled estimate.
+
+This is the Python twin of julia/mcmc_eap_chain.jl (no Julia toolchain exists in the build image);
+both are thin: every number they print comes out of the library.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import sys
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .ensemble import Ensemble, summary_from_reduction
+from .julia_fmt import jl_float, jl_row, jl_vector
+
+TRAJ_HEADER = "step,r1,r2,r3,p1,p2,p3,U"
+ROLL_HEADER = "step,r1,r2,r3,r1sq,r2sq,r3sq,rsq,p1,p2,p3,p1sq,p2sq,p3sq,psq,U,Usq"
+
+
+class ReferenceError_(RuntimeError):
+    """Raised where the reference calls error(...) -- same message text."""
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(prog="mcmc_eap_chain", add_help=True, allow_abbrev=False)
+    a = p.add_argument
+    # --- the reference's table, mcmc_eap_chain.jl:19-153 (dest = ArgParse.jl's dict key)
+    a("--E0", "-e", dest="E0", type=float, default=0.0, help="magnitude of electric field")
+    a("--chain-type", "-T", dest="chain-type", type=str, default="dielectric", help="chain type (dielectric|polar)")
+    a("--K1", "-J", dest="K1", type=float, default=1.0, help="dipole susceptibility along the monomer axis (dielectric chain)")
+    a("--K2", "-K", dest="K2", type=float, default=0.0, help="dipole susceptibility orthogonal to the monomer axis (dielectric chain)")
+    a("--mu", "-m", dest="mu", type=float, default=1e-2, help="dipole magnitude (electret chain)")
+    a("--energy-type", "-u", dest="energy-type", type=str, default="noninteracting", help="energy type (noninteracting|interacting)")
+    a("--kT", "-k", dest="kT", type=float, default=1.0, help="dimensionless temperature")
+    a("--ensemble-type", "-E", dest="ensemble-type", type=str, default="force", help="ensemble type (force|end-to-end)")
+    a("--Fz", "-F", dest="Fz", type=float, default=0.0, help="force in the z-direction (direction of E-field; force ensemble)")
+    a("--Fx", "-G", dest="Fx", type=float, default=0.0, help="force in the x-direction (force ensemble)")
+    a("--rz", "-z", dest="rz", type=float, default=0.0, help="end-to-end vector in the z-direction (etoe ensemble)")
+    a("--rx", "-x", dest="rx", type=float, default=0.0, help="end-to-end vector in the x-direction (etoe ensemble)")
+    a("--mlen", "-b", dest="mlen", type=float, default=1.0, help="monomer length")
+    a("--num-monomers", "-n", dest="num-monomers", type=int, default=100, help="number of monomers")
+    a("--num-steps", "-N", dest="num-steps", type=int, default=int(1e5), help="number of steps")
+    a("--num-inits", "-M", dest="num-inits", type=int, default=1, help="number of random initializations")
+    a("--force-init", "-I", dest="force-init", action="store_true", help="force each random initialization (false to use metro.)")
+    a("--phi-step", "-p", dest="phi-step", type=float, default=3 * math.pi / 8, help="maximum phi step length")
+    a("--do-flips", dest="do-flips", action="store_true", help="trial moves with flipping monomers")
+    a("--theta-step", "-q", dest="theta-step", type=float, default=3 * math.pi / 16, help="maximum theta step length")
+    a("--chain-frac-step", "-f", dest="chain-frac-step", type=float, default=0.15, help="fraction of monomers to step (end-to-end ensemble)")
+    a("--step-adjust-lb", "-L", dest="step-adjust-lb", type=float, default=0.15, help="adjust step sizes if acc. ratio below this threshold")
+    a("--step-adjust-ub", "-U", dest="step-adjust-ub", type=float, default=0.55, help="adjust step sizes if acc. ratio above this threshold")
+    a("--step-adjust-scale", "-A", dest="step-adjust-scale", type=float, default=1.1, help="scale factor for adjusting step sizes (> 1.0)")
+    a("--steps-per-adjust", "-S", dest="steps-per-adjust", type=int, default=2500, help="steps between step size adjustments")
+    a("--acc", "-a", dest="acc", type=str, default="metropolis", help="acceptance function (metropolis|kawasaki)")
+    a("--umbrella-sampling", "-B", dest="umbrella-sampling", action="store_true", help="use umbrella sampling (w/ electrostatic weight function)")
+    a("--update-freq", dest="update-freq", type=float, default=15.0, help="update frequency (seconds)")
+    a("--verbose", "-v", dest="verbose", type=int, default=3, help="verbosity level: 0-nothing, 1-errors, 2-warnings, 3-info")
+    a("--prefix", "-P", dest="prefix", type=str, default="eap-mcmc", help="prefix for output files")
+    a("--postfix", "-Q", dest="postfix", type=str, default="", help="postfix for output files")
+    a("--stepout", "-s", dest="stepout", type=int, default=500, help="steps between storing microstates")
+    a("--numeric-type", dest="numeric-type", type=str, default="float64", help="numerical data type for averaging (float64|float128|dec128|big)")
+    a("--profile", "-Z", dest="profile", action="store_true", help="profile the program")
+    # --- ours
+    a("--num-chains", dest="num-chains", type=int, default=4096, help="independent chains run at once on the GPU(s) and pooled")
+    a("--seed", dest="seed", type=int, default=0, help="seed of the per-chain counter-seeded generators")
+    a("--devices", dest="devices", type=str, default="0", help="comma-separated HIP device ordinals; chains are sharded over them")
+    a("--precision", dest="precision", type=str, default="f32", help="device arithmetic: f32 (f64 running sums) | f64")
+    return p
+
+
+def parse_args(argv=None) -> dict:
+    return vars(build_parser().parse_args(argv))
+
+
+def default_pargs(**overrides) -> dict:
+    d = parse_args([])
+    for k, v in overrides.items():
+        if k not in d:
+            raise KeyError(k)
+        d[k] = v
+    return d
+
+
+def _log(pargs, level: int, tag: str, msg: str):
+    # Logging to stderr gated by --verbose (mcmc_eap_chain.jl:157-165): 3 info, 2 warn, 1 error
+    if pargs["verbose"] >= level:
+        print(f"[ {tag}: {msg}", file=sys.stderr)
+
+
+def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int) -> _lib.Params:
+    """pargs -> pstat_params, with the reference's error() branches (inc/eap_chain.jl:81-105)."""
+    ct = {"dielectric": _lib.DIELECTRIC, "polar": _lib.POLAR}.get(pargs["chain-type"])
+    if ct is None:
+        raise ReferenceError_("chain-type is not understood.")
+    et = {"noninteracting": _lib.NONINTERACTING, "interacting": _lib.INTERACTING,
+          "Ising": _lib.ISING}.get(pargs["energy-type"])
+    if et is None:
+        raise ReferenceError_("energy-type is not understood.")
+    prec = {"f32": _lib.F32, "f64": _lib.F64}.get(pargs["precision"])
+    if prec is None:
+        raise ReferenceError_(f"precision '{pargs['precision']}' not understood")
+    return _lib.default_params(
+        E0=pargs["E0"], K1=pargs["K1"], K2=pargs["K2"], mu=pargs["mu"], kT=pargs["kT"],
+        Fz=pargs["Fz"], Fx=pargs["Fx"], b=pargs["mlen"],
+        phi_step=pargs["phi-step"], theta_step=pargs["theta-step"],
+        adj_lb=pargs["step-adjust-lb"], adj_ub=pargs["step-adjust-ub"], adj_scale=pargs["step-adjust-scale"],
+        steps_per_adjust=pargs["steps-per-adjust"], n=pargs["num-monomers"], num_chains=num_chains,
+        seed=pargs["seed"], chain_id0=chain_id0, chain_type=ct, energy_type=et,
+        do_flips=1 if pargs["do-flips"] else 0, umbrella=1 if pargs["umbrella-sampling"] else 0,
+        precision=prec, device=device)
+
+
+@dataclass
+class Averager:
+    """What the caller of mcmc() gets back in place of a StandardAverager (inc/average.jl:8-48)."""
+    value: object
+    stderr: object
+
+    def get_avg(self):
+        return self.value
+
+
+def get_avg(a: Averager):
+    return a.get_avg()
+
+
+class _Pool:
+    """Chains sharded over one or more devices in this process; reductions merged on the host
+    (every entry of the reduction vector is additive)."""
+
+    def __init__(self, pargs: dict):
+        devices = [int(d) for d in str(pargs["devices"]).split(",") if d != ""]
+        total = int(pargs["num-chains"])
+        if total < 1:
+            raise ReferenceError_("num-chains must be >= 1")
+        devices = devices[:total] or [0]
+        base, extra = divmod(total, len(devices))
+        self.parts = []
+        first = 0
+        for i, dev in enumerate(devices):
+            cnt = base + (1 if i < extra else 0)
+            self.parts.append(Ensemble(params_from_pargs(pargs, cnt, first, dev)))
+            first += cnt
+        self.steps = 0
+
+    def advance(self, n):
+        for e in self.parts:
+            e.advance(n)            # asynchronous: the devices run concurrently
+        self.steps += n
+
+    def reinit(self, force):
+        for e in self.parts:
+            e.reinit(force)
+
+    def summary(self):
+        red = np.zeros(_lib.NRED)
+        for e in self.parts:
+            red += e.reduce_host(-1)
+        return summary_from_reduction(red, self.steps)
+
+    def microstate(self):
+        return self.parts[0].microstate(0)
+
+    def close(self):
+        for e in self.parts:
+            e.close()
+
+
+def mcmc(nsteps: int, pargs: dict):
+    """mcmc(nsteps, pargs) of mcmc_eap_chain.jl:171-376 -> (scalar_averagers, vector_averagers, ar)."""
+    if pargs["acc"] != "metropolis":
+        raise ReferenceError_(f"'{pargs['acc']}' acceptance criteria has not yet been implemented.")  # :184
+    if pargs["numeric-type"] not in ("float64", "float128", "dec128", "big"):
+        raise ReferenceError_(f"numeric-type '{pargs['numeric-type']}' not understood")                # :195
+    if pargs["numeric-type"] != "float64":
+        _log(pargs, 2, "Warning", "per-chain sums are kept in Float64 on the device; "
+                                  f"'{pargs['numeric-type']}' only affects nothing here")
+    if pargs["ensemble-type"] != "force":
+        raise ReferenceError_("'end-to-end' ensemble is an experimental option of the reference; "
+                              "it has no device implementation")
+    pool = _Pool(pargs)
+    stepout = int(pargs["stepout"])
+    try:
+        with open(f"{pargs['prefix']}_trajectory.csv", "w") as outfile, \
+                open(f"{pargs['prefix']}_rolling.csv", "w") as rollfile:
+            outfile.write(TRAJ_HEADER + "\n")       # :257
+            rollfile.write(ROLL_HEADER + "\n")      # :259
+            start = last_update = time.time()
+            for init in range(1, pargs["num-inits"] + 1):           # :266
+                step = 0
+                while step < nsteps:                                # :276 (in segments)
+                    seg = nsteps - step
+                    if stepout > 0:
+                        seg = min(seg, stepout - step % stepout)
+                    pool.advance(seg)
+                    step += seg
+                    if time.time() - last_update > pargs["update-freq"]:   # :294-299
+                        _log(pargs, 3, "Info", f"elapsed: {time.time() - start}")
+                        _log(pargs, 3, "Info", f"init:    {init} / {pargs['num-inits']}")
+                        _log(pargs, 3, "Info", f"step:    {step} / {nsteps}")
+                        last_update = time.time()
+                    if stepout > 0 and step % stepout == 0:          # :329-348
+                        micro = pool.microstate()
+                        s = pool.summary()
+                        outfile.write(jl_row([step, *micro]) + "\n")
+                        rollfile.write(jl_row([step, *s.avg]) + "\n")
+                if init < pargs["num-inits"]:                        # :352-361
+                    pool.reinit(bool(pargs["force-init"]))
+        s = pool.summary()
+        _log(pargs, 3, "Info", f"total time elapsed: {time.time() - start}")
+        _log(pargs, 3, "Info", f"acceptance rate: {s.acceptance_ratio}")
+    finally:
+        pool.close()
+    avg, se = np.array(s.avg), np.array(s.stderr)
+    sas = [Averager(avg[6], se[6]), Averager(avg[13], se[13]), Averager(avg[14], se[14]), Averager(avg[15], se[15])]
+    vas = [Averager(avg[0:3], se[0:3]), Averager(avg[3:6], se[3:6]), Averager(avg[7:10], se[7:10]),
+           Averager(avg[10:13], se[10:13])]
+    return sas, vas, s.acceptance_ratio
+
+
+def summary_lines(sas, vas, ar, pargs) -> list[str]:
+    """The ten println lines, mcmc_eap_chain.jl:386-395."""
+    nb = pargs["mlen"] * pargs["num-monomers"]
+    return [
+        f"<r>    =   {jl_vector(get_avg(vas[0]))}",
+        f"<r/nb> =   {jl_vector(np.asarray(get_avg(vas[0])) / nb)}",
+        f"<rj2>  =   {jl_vector(get_avg(vas[1]))}",
+        f"<r2>   =   {jl_float(get_avg(sas[0]))}",
+        f"<p>    =   {jl_vector(get_avg(vas[2]))}",
+        f"<pj2>  =   {jl_vector(get_avg(vas[3]))}",
+        f"<p2>   =   {jl_float(get_avg(sas[1]))}",
+        f"<U>    =   {jl_float(get_avg(sas[2]))}",
+        f"<U2>   =   {jl_float(get_avg(sas[3]))}",
+        f"AR     =   {jl_float(ar)}",
+    ]
+
+
+def main(argv=None) -> int:
+    pargs = parse_args(argv)
+    if pargs["ensemble-type"] == "end-to-end":
+        _log(pargs, 2, "Warning", "'end-to-end' ensemble is an experimental option; it has not been validated.")
+    if pargs["profile"]:
+        raise ReferenceError_("not implemented for the HPC env")     # :379
+    sas, vas, ar = mcmc(pargs["num-steps"], pargs)
+    for line in summary_lines(sas, vas, ar, pargs):
+        print(line)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

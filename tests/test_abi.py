@@ -1,0 +1,97 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/pstat.h declares, its structs
+have the layout the bindings assume, and it fails loudly (no CPU fallback).  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ps():
+    import polymer_stats_amd as ps
+    ps._lib.load()
+    return ps
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pstat.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pstat_[a-z_]+)\s*\(", text)))
+
+
+def test_exports_every_declared_symbol(ps):
+    lib = ps._lib.load()
+    names = declared_symbols()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"libpstat.so does not export {n}"
+    assert sorted(ps._lib.SYMBOLS) == names, "binding's symbol list is out of date"
+    assert lib.pstat_abi_version() == 1
+
+
+def test_struct_layout_matches_header(ps, tmp_path):
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pstat.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(pstat_params), offsetof(pstat_params, steps_per_adjust),'
+                   'offsetof(pstat_params, seed), offsetof(pstat_params, device), sizeof(pstat_summary),'
+                   'offsetof(pstat_summary, num_chains), sizeof(pstat_launch_info));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    P, S, LI = ps._lib.Params, ps._lib.Summary, ps._lib.LaunchInfo
+    assert got == [C.sizeof(P), P.steps_per_adjust.offset, P.seed.offset, P.device.offset, C.sizeof(S),
+                   S.num_chains.offset, C.sizeof(LI)]
+
+
+def test_defaults_are_the_references(ps):
+    import math
+    p = ps.default_params()
+    # mcmc_eap_chain.jl:19-153
+    assert (p.E0, p.K1, p.K2, p.mu, p.kT, p.Fz, p.Fx, p.b) == (0.0, 1.0, 0.0, 1e-2, 1.0, 0.0, 0.0, 1.0)
+    assert p.phi_step == 3 * math.pi / 8 and p.theta_step == 3 * math.pi / 16
+    assert (p.adj_lb, p.adj_ub, p.adj_scale, p.steps_per_adjust) == (0.15, 0.55, 1.1, 2500)
+    assert p.n == 100 and p.chain_type == ps.DIELECTRIC and p.energy_type == ps.NONINTERACTING
+
+
+def test_strerror_and_invalid_arguments(ps):
+    lib = ps._lib.load()
+    assert lib.pstat_strerror(0) == b"ok"
+    assert b"device" in lib.pstat_strerror(-2)
+    h = C.c_void_p()
+    for bad in (dict(n=0), dict(kT=-1.0), dict(chain_type=7), dict(energy_type=9), dict(num_chains=0),
+                dict(precision=5), dict(phi_step=0.0)):
+        p = ps.default_params(**bad)
+        rc = lib.pstat_create(C.byref(p), 1, None, C.byref(h))
+        assert rc == -1, (bad, rc)
+        assert lib.pstat_last_error() != b""
+    assert lib.pstat_create(None, 1, None, C.byref(h)) == -1
+    assert lib.pstat_advance(None, 10) == -1
+
+
+def test_no_cpu_fallback(ps):
+    """Without a GPU every compute entry point refuses; with one this test is skipped."""
+    lib = ps._lib.load()
+    if lib.pstat_device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(ps.PstatError) as ei:
+        ps.Ensemble(ps.default_params(n=10))
+    assert ei.value.code == -2 and "no CPU path" in str(ei.value)
+
+
+def test_product_never_touches_the_oracle():
+    """The package may not import, load or name anything under oracle/."""
+    pkg = os.path.join(ROOT, "polymer_stats_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                code = "\n".join(l for l in text.splitlines() if "oracle" in l.lower()
+                                 and not l.strip().startswith(("//", "#", "*", "/*", '"""')))
+                assert "liboracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+                assert "eap_oracle" not in code, (f, code)
+    out = subprocess.check_output(["ldd", os.path.join(pkg, "libpstat.so")]).decode()
+    assert "oracle" not in out

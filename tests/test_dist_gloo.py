@@ -1,0 +1,59 @@
+"""N > 1 path on CPU: two processes (gloo) each own a shard of the chains (disjoint global chain
+ids), build their reduction vectors and merge them with ONE all-reduce(SUM) -- exactly what
+bench.py / a multi-GPU job does with RCCL.  The merged summary must equal the single-process one.
+The per-chain numbers come from the CPU oracle (this is a test); the merge arithmetic is the
+library's own host function pstat_summary_from_reduction."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NCHAINS, NSTEPS = 24, 3000
+
+
+def reduction_vector(sums, norm, nacc, steps):
+    m = np.concatenate([sums / norm[:, None], (nacc / steps)[:, None]], axis=1)
+    return np.concatenate([[m.shape[0]], m.sum(0), (m ** 2).sum(0)])
+
+
+def worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import binding as ob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = ob.make_params(n=10, E0=1.0, K1=1.0, Fz=0.5, num_steps=NSTEPS, seed=5)
+    per = NCHAINS // world
+    sums, norm, nacc = ob.run_many(P, rank * per, per, nthreads=2, mode="fast")   # shard by global chain id
+    red = torch.from_numpy(reduction_vector(sums, norm, nacc, NSTEPS))
+    dist.all_reduce(red)                                                          # the one collective
+    if rank == 0:
+        np.save(out, red.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_merge_equals_single_process(tmp_path, oracle):
+    import polymer_stats_amd as ps
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "red.npy")
+    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    merged = np.load(out)
+    P = oracle.make_params(n=10, E0=1.0, K1=1.0, Fz=0.5, num_steps=NSTEPS, seed=5)
+    sums, norm, nacc = oracle.run_many(P, 0, NCHAINS, nthreads=4, mode="fast")
+    single = reduction_vector(sums, norm, nacc, NSTEPS)
+    np.testing.assert_allclose(merged, single, rtol=1e-12)
+    s = ps.summary_from_reduction(merged, NSTEPS)
+    m = sums / norm[:, None]
+    np.testing.assert_allclose(np.array(s.avg), m.mean(0), rtol=1e-12)
+    np.testing.assert_allclose(np.array(s.stderr), m.std(0, ddof=1) / np.sqrt(NCHAINS), rtol=1e-8)
+    assert s.num_chains == NCHAINS

@@ -1,0 +1,103 @@
+"""CPU tests of the host mirror of the reference's interface (polymer_stats_amd/mcmc_eap_chain.py,
+julia_fmt.py): option table, error behaviour, output formatting, reduction -> summary arithmetic."""
+import math
+
+import numpy as np
+import pytest
+
+import polymer_stats_amd as ps
+from polymer_stats_amd import mcmc_eap_chain as host
+from polymer_stats_amd.julia_fmt import jl_float, jl_row, jl_vector
+
+# (long flag, short alias, default) read off mcmc_eap_chain.jl:19-153
+REFERENCE_TABLE = [
+    ("--E0", "-e", 0.0), ("--chain-type", "-T", "dielectric"), ("--K1", "-J", 1.0), ("--K2", "-K", 0.0),
+    ("--mu", "-m", 1e-2), ("--energy-type", "-u", "noninteracting"), ("--kT", "-k", 1.0),
+    ("--ensemble-type", "-E", "force"), ("--Fz", "-F", 0.0), ("--Fx", "-G", 0.0), ("--rz", "-z", 0.0),
+    ("--rx", "-x", 0.0), ("--mlen", "-b", 1.0), ("--num-monomers", "-n", 100), ("--num-steps", "-N", 100000),
+    ("--num-inits", "-M", 1), ("--force-init", "-I", False), ("--phi-step", "-p", 3 * math.pi / 8),
+    ("--do-flips", None, False), ("--theta-step", "-q", 3 * math.pi / 16), ("--chain-frac-step", "-f", 0.15),
+    ("--step-adjust-lb", "-L", 0.15), ("--step-adjust-ub", "-U", 0.55), ("--step-adjust-scale", "-A", 1.1),
+    ("--steps-per-adjust", "-S", 2500), ("--acc", "-a", "metropolis"), ("--umbrella-sampling", "-B", False),
+    ("--update-freq", None, 15.0), ("--verbose", "-v", 3), ("--prefix", "-P", "eap-mcmc"), ("--postfix", "-Q", ""),
+    ("--stepout", "-s", 500), ("--numeric-type", None, "float64"), ("--profile", "-Z", False),
+]
+
+
+def test_option_table_matches_reference():
+    assert len(REFERENCE_TABLE) == 34
+    d = host.parse_args([])
+    for long, short, default in REFERENCE_TABLE:
+        key = long[2:]
+        assert key in d, key
+        assert d[key] == default and type(d[key]) is type(default), (key, d[key], default)
+    # every short alias parses to the same key
+    for long, short, default in REFERENCE_TABLE:
+        if short is None:
+            continue
+        val = {bool: None, int: "7", float: "0.25", str: "polar"}[type(default)]
+        argv = [short] if val is None else [short, val]
+        got = host.parse_args(argv)[long[2:]]
+        assert got == (True if val is None else type(default)(val)), (short, got)
+
+
+def test_julia_float_formatting():
+    cases = [(500.0, "500.0"), (35.02, "35.02"), (1e-5, "1.0e-5"), (0.0001, "0.0001"), (1e6, "1.0e6"),
+             (999999.0, "999999.0"), (123456789012345678.0, "1.2345678901234568e17"), (-6.2875452, "-6.2875452"),
+             (1.5e-7, "1.5e-7"), (0.1 + 0.2, "0.30000000000000004"), (0.0, "0.0"), (-0.0, "-0.0"), (1e21, "1.0e21"),
+             (2.5e-5, "2.5e-5"), (float("inf"), "Inf"), (float("-inf"), "-Inf")]
+    for x, want in cases:
+        assert jl_float(x) == want, (x, jl_float(x), want)
+    assert jl_float(float("nan")) == "NaN"
+    # round trip through the parser the consumers use (a Julia literal is also a Python literal here)
+    rng = np.random.default_rng(0)
+    for x in np.concatenate([rng.normal(size=200) * 10.0 ** rng.integers(-12, 12, 200), [1e-300, 1e300]]):
+        assert float(jl_float(x)) == x
+    assert jl_vector([1.0, -2.5, 1e-7]) == "[1.0, -2.5, 1.0e-7]"
+    assert jl_row([500, 1.25, -3.0]) == "500.0,1.25,-3.0"    # `step` prints as a Float64 (hcat promotes)
+
+
+def test_summary_lines_shape():
+    avg = np.arange(1.0, 17.0)
+    sas = [host.Averager(avg[6], 0), host.Averager(avg[13], 0), host.Averager(avg[14], 0), host.Averager(avg[15], 0)]
+    vas = [host.Averager(avg[0:3], 0), host.Averager(avg[3:6], 0), host.Averager(avg[7:10], 0), host.Averager(avg[10:13], 0)]
+    lines = host.summary_lines(sas, vas, 0.6, host.default_pargs(**{"num-monomers": 10, "mlen": 2.0}))
+    assert [l.split("=")[0].strip() for l in lines] == ["<r>", "<r/nb>", "<rj2>", "<r2>", "<p>", "<pj2>", "<p2>", "<U>", "<U2>", "AR"]
+    assert lines[0] == "<r>    =   [1.0, 2.0, 3.0]"
+    assert lines[1] == "<r/nb> =   [0.05, 0.1, 0.15]"
+    assert lines[3] == "<r2>   =   7.0" and lines[9] == "AR     =   0.6"
+    # the consumers split on '=' and eval the right-hand side (scripts/aggregate_mcmc.jl:71)
+    for l in lines:
+        rhs = l.split("=")[1]
+        assert np.all(np.isfinite(np.array(eval(rhs), dtype=float)))
+
+
+def test_reference_error_branches():
+    with pytest.raises(host.ReferenceError_, match="acceptance criteria has not yet been implemented"):
+        host.mcmc(10, host.default_pargs(acc="kawasaki"))
+    with pytest.raises(host.ReferenceError_, match="numeric-type 'float16' not understood"):
+        host.mcmc(10, host.default_pargs(**{"numeric-type": "float16"}))
+    with pytest.raises(host.ReferenceError_, match="chain-type is not understood."):
+        host.params_from_pargs(host.default_pargs(**{"chain-type": "rod"}), 1, 0, 0)
+    with pytest.raises(host.ReferenceError_, match="energy-type is not understood."):
+        host.params_from_pargs(host.default_pargs(**{"energy-type": "cutoff"}), 1, 0, 0)
+    with pytest.raises(host.ReferenceError_, match="not implemented for the HPC env"):
+        host.main(["--profile"])
+    p = host.params_from_pargs(host.default_pargs(**{"energy-type": "Ising", "chain-type": "polar", "mlen": 2.0,
+                                                     "do-flips": True}), 128, 64, 0)
+    assert (p.energy_type, p.chain_type, p.b, p.do_flips, p.num_chains, p.chain_id0) == (ps.ISING, ps.POLAR, 2.0, 1, 128, 64)
+
+
+def test_summary_from_reduction_is_pooled_mean_and_stderr():
+    rng = np.random.default_rng(1)
+    C = 37
+    m = rng.normal(size=(C, 17)) + 5.0          # per-chain means: 16 observables + acceptance ratio
+    red = np.zeros(ps.NRED)
+    red[0] = C
+    red[1:18] = m.sum(0)
+    red[18:35] = (m ** 2).sum(0)
+    s = ps.summary_from_reduction(red, 1000)
+    np.testing.assert_allclose(np.array(s.avg), m[:, :16].mean(0), rtol=1e-13)
+    np.testing.assert_allclose(np.array(s.stderr), m[:, :16].std(0, ddof=1) / np.sqrt(C), rtol=1e-9)
+    assert s.acceptance_ratio == pytest.approx(m[:, 16].mean())
+    assert s.num_chains == C and s.steps_per_chain == 1000 and s.attempted_updates == C * 1000.0

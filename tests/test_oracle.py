@@ -1,0 +1,177 @@
+"""CPU tests of the oracle (oracle/eap_oracle.c) -- the checker must itself be checked.
+
+Pins available (the reference ships none -- "parity unpinned", see oracle/eap_oracle.h):
+  * Philox4x32-10 known-answer vectors of Random123 (kat_vectors), xoshiro128++ against an
+    independent pure-Python transcription of the published algorithm;
+  * closed-form equilibrium averages (tests/golden/ni_closed_form.json);
+  * hand-computable dipole-dipole energies (inc/eap_chain.jl:200-207);
+  * literal ("faithful") and incremental ("fast") restatements making identical decisions.
+"""
+import numpy as np
+import pytest
+
+from helpers import pooled
+
+M32 = 0xFFFFFFFF
+
+
+def test_philox_known_answers(oracle):
+    assert oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox([M32] * 4, [M32] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_xoshiro128pp_matches_published_algorithm(oracle):
+    def rotl(x, k):
+        return ((x << k) | (x >> (32 - k))) & M32
+    seed, chain = 0x1234_5678_9abc_def0, 42
+    s, got = oracle.xoshiro_stream(seed, chain, 1000)
+    # seeding contract: Philox(key=seed, ctr=(chain_lo, chain_hi, 0x5eed, 0))
+    assert s == oracle.philox([chain & M32, chain >> 32, 0x5eed, 0], [seed & M32, seed >> 32])
+    want = []
+    for _ in range(1000):
+        want.append((rotl((s[0] + s[3]) & M32, 7) + s[0]) & M32)
+        t = (s[1] << 9) & M32
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = rotl(s[3], 11)
+    assert got == want
+    # distinct chains get distinct streams
+    assert oracle.xoshiro_stream(seed, chain + 1, 4)[1] != got[:4]
+
+
+def test_uniform_contract(oracle):
+    L = oracle.lib()
+    assert L.eap_u01(0) == 0.0
+    assert L.eap_u01(M32) == 1.0 - 2.0 ** -23
+    assert L.eap_u01(1 << 9) == 2.0 ** -23
+
+
+def test_pair_energy_by_hand(oracle):
+    # two dipoles along z, separated along z by d: head-to-tail, U = (1 - 3)/(4 pi d^3) * m1 m2
+    d, m1, m2 = 1.7, 0.8, 1.3
+    xs = np.array([[0, 0, 0], [0, 0, d]], float)
+    mus = np.array([[0, 0, m1], [0, 0, m2]], float)
+    assert oracle.pair_energy(xs, mus) == pytest.approx(-2 * m1 * m2 / (4 * np.pi * d ** 3), rel=1e-14)
+    # side by side (separated along x), parallel: U = + m1 m2 / (4 pi d^3)
+    xs = np.array([[0, 0, 0], [d, 0, 0]], float)
+    assert oracle.pair_energy(xs, mus) == pytest.approx(m1 * m2 / (4 * np.pi * d ** 3), rel=1e-14)
+    # three collinear along x, dipoles along x: pairs (1,2),(2,3) at d and (1,3) at 2d
+    xs = np.array([[0, 0, 0], [d, 0, 0], [2 * d, 0, 0]], float)
+    mus = np.array([[m1, 0, 0]] * 3, float)
+    want = -2 * m1 * m1 / (4 * np.pi) * (2 / d ** 3 + 1 / (2 * d) ** 3)
+    assert oracle.pair_energy(xs, mus) == pytest.approx(want, rel=1e-14)
+    # Ising = nearest neighbours only
+    assert oracle.pair_energy(xs, mus, ising=True) == pytest.approx(-2 * m1 * m1 / (4 * np.pi) * 2 / d ** 3, rel=1e-14)
+
+
+def test_chain_energy_straight_chain(oracle):
+    # all monomers along z: theta = 0 -> r = n b z, dielectric mu_i = K1 E0 z, u_i = -E0^2 K1 / 2
+    n, E0, K1, K2, b, Fz = 5, 1.5, 0.7, 0.3, 1.3, 0.4
+    P = oracle.make_params(n=n, E0=E0, K1=K1, K2=K2, b=b, Fz=Fz, Fx=0.2)
+    U, r, p = oracle.chain_energy(P, np.zeros(n), np.zeros(n))
+    np.testing.assert_allclose(r, [0, 0, n * b], atol=1e-14)
+    np.testing.assert_allclose(p, [0, 0, n * K1 * E0], atol=1e-14)
+    assert U == pytest.approx(-0.5 * E0 * n * K1 * E0 - Fz * n * b, rel=1e-14)
+    # interacting: + sum over pairs of collinear head-to-tail dipoles m = K1 E0 at distance |i-j| b
+    Pi = oracle.make_params(n=n, E0=E0, K1=K1, K2=K2, b=b, Fz=Fz, energy_type=oracle.INTERACTING)
+    Ui, _, _ = oracle.chain_energy(Pi, np.zeros(n), np.zeros(n))
+    m = K1 * E0
+    pairs = sum(-2 * m * m / (4 * np.pi * ((j - i) * b) ** 3) for i in range(n) for j in range(i + 1, n))
+    assert Ui - U == pytest.approx(pairs, rel=1e-12)
+    # polar: mu = mu n, u = -E0 mu cos(theta) / 2 (the 1/2 applies to polar chains too: eap_chain.jl:53)
+    Pp = oracle.make_params(n=n, E0=E0, mu=0.9, chain_type=oracle.POLAR, b=b)
+    Up, _, pp = oracle.chain_energy(Pp, np.zeros(n), np.full(n, np.pi / 3))
+    assert Up == pytest.approx(-0.5 * E0 * 0.9 * n * 0.5, rel=1e-13)
+    assert pp[2] == pytest.approx(0.9 * n * 0.5, rel=1e-13)
+
+
+CASES = [
+    dict(n=20, E0=0.0, Fz=1.0),
+    dict(n=33, E0=1.5, K1=0.7, K2=0.3, Fz=0.4, Fx=0.3, kT=0.7, b=1.3, do_flips=1, steps_per_adjust=500),
+    dict(n=16, E0=1.0, mu=1.0, Fz=1.0, chain_type=1),
+    dict(n=12, E0=1.0, K1=1.0, Fz=0.25, energy_type=2, steps_per_adjust=400),
+    dict(n=10, E0=1.0, K1=1.0, Fz=0.5, energy_type=1, steps_per_adjust=400),
+    dict(n=14, E0=1.0, K1=1.0, K2=0.2, Fz=0.5, umbrella=1),
+    dict(n=9, E0=1.0, mu=0.5, Fz=0.2, chain_type=1, umbrella=1, energy_type=2),
+    dict(n=1, E0=2.0, K1=1.0, Fz=0.5, adj_scale=1.0),
+]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_faithful_and_fast_agree(oracle, kw):
+    """Same stream -> same accept/reject sequence, same final angles, same generator state; running
+    sums equal to rounding.  This is what licenses the O(1)-energy form the kernels use."""
+    for inits, force in ((1, 0), (3, 1), (3, 0)):
+        P = oracle.make_params(num_steps=4000, num_inits=inits, force_init=force, seed=17, stepout=500, **kw)
+        a = oracle.run(P, 3, "faithful", trace=True, rows=True)
+        b = oracle.run(P, 3, "fast", trace=True, rows=True)
+        assert np.array_equal(a.accepted, b.accepted)
+        assert np.array_equal(a.final_theta, b.final_theta) and np.array_equal(a.final_phi, b.final_phi)
+        assert np.array_equal(a.rng, b.rng)
+        assert a.nacc_total == b.nacc_total and (a.phi_step, a.theta_step) == (b.phi_step, b.theta_step)
+        np.testing.assert_allclose(a.avg, b.avg, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(a.rolling, b.rolling, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(a.traj, b.traj, rtol=1e-9, atol=1e-9)
+        assert a.rolling.shape == (inits * 8, 17) and a.rolling[0, 0] == 500.0
+
+
+def test_interacting_reduces_to_noninteracting_without_dipoles(oracle):
+    # E0 = 0 -> all dipoles vanish -> pair energy identically 0 -> same chain as non-interacting
+    kw = dict(n=12, E0=0.0, Fz=0.7, num_steps=3000, seed=4)
+    a = oracle.run(oracle.make_params(**kw), 0, "fast", trace=True)
+    b = oracle.run(oracle.make_params(energy_type=oracle.INTERACTING, **kw), 0, "faithful", trace=True)
+    assert np.array_equal(a.accepted, b.accepted)
+    np.testing.assert_allclose(a.avg, b.avg, rtol=1e-10, atol=1e-12)
+
+
+def test_adaptation_saturates_in_weak_field(oracle):
+    # config 1 accepts ~60 % > ub, so the step sizes grow by 1.1 eleven times and cap
+    P = oracle.make_params(n=20, E0=0.0, Fz=1.0, num_steps=100000, seed=1)
+    r = oracle.run(P, 0, "fast")
+    assert r.phi_step == np.pi and r.theta_step == np.pi / 2
+    assert 0.55 < r.ar < 0.65
+
+
+def test_rejected_when_clamped_to_zero(oracle):
+    # theta' clamped to exactly 0 -> sin = 0 -> log-density -inf -> always rejected:
+    # with a huge theta step half the proposals clamp, so the acceptance ratio must stay < 0.5+
+    P = oracle.make_params(n=4, E0=0.0, Fz=0.0, num_steps=20000, theta_step=50.0, phi_step=1.0,
+                           adj_scale=1.0, seed=2)
+    r = oracle.run(P, 0, "fast", trace=True)
+    assert r.ar < 0.05
+    assert np.all(r.final_theta > 0) and np.all(r.final_theta <= np.pi)
+
+
+@pytest.mark.parametrize("name,nsteps,nch", [
+    ("cfg1_n20_E0_0_Fz1", 100000, 48),
+    ("diel_n8_E0_15_K1_07_K2_03_Fz04_Fx03_kT07_b13", 100000, 48),
+])
+def test_oracle_against_closed_form(oracle, golden, name, nsteps, nch):
+    """Pooled oracle averages vs single-monomer quadrature.  The estimator has no burn-in, so a
+    transient of relative size ~tau/N (tau ~ 10 n steps) is allowed on top of 4.5 standard errors."""
+    g = golden[name]
+    c = g["params"]
+    P = oracle.make_params(n=c["n"], E0=c["E0"], K1=c["K1"], K2=c["K2"], mu=c["mu"], kT=c["kT"], Fz=c["Fz"],
+                           Fx=c["Fx"], b=c["b"], chain_type=oracle.POLAR if c["chain"] == "polar" else oracle.DIELECTRIC,
+                           num_steps=nsteps, seed=99)
+    sums, norm, _ = oracle.run_many(P, 0, nch, nthreads=8, mode="fast")
+    avg, se = pooled(sums, norm)
+    tau_over_N = 10.0 * c["n"] / nsteps
+    for k, name_k in enumerate(oracle.OBS_NAMES):
+        want = g["avg"][name_k]
+        tol = 4.5 * se[k] + 3 * tau_over_N * (abs(want) + 1.0)
+        assert abs(avg[k] - want) < tol, (name_k, avg[k], want, se[k])
+
+
+def test_umbrella_and_standard_estimate_the_same_averages(oracle):
+    """The reference's own validation idea (run/noninteracting-compare-with-clustering_2021-09-24.jl):
+    umbrella-weighted and plain sampling must agree."""
+    kw = dict(n=10, E0=0.8, K1=1.0, K2=0.0, Fz=0.3, num_steps=60000, seed=8)
+    s0, n0, _ = oracle.run_many(oracle.make_params(**kw), 0, 48, nthreads=8, mode="fast")
+    s1, n1, _ = oracle.run_many(oracle.make_params(umbrella=1, **kw), 1000, 48, nthreads=8, mode="fast")
+    a0, e0 = pooled(s0, n0)
+    a1, e1 = pooled(s1, n1)
+    z = (a0 - a1) / np.sqrt(e0 ** 2 + e1 ** 2 + 1e-300)
+    assert np.all(np.abs(z) < 4.5), z
