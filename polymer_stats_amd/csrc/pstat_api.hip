@@ -56,6 +56,8 @@ struct pstat_handle {
   SweepArgs args{};
   DevState S{};
   std::vector<Buffer> bufs;         // every device allocation, in checkpoint order
+  int *d_queue = nullptr;           // sweep job queue: counter, error flag, per-block progress
+  int slots = 0;                    // resident sweep workgroups on the whole device
   double *d_partial = nullptr;      // reduction scratch
   double *d_red = nullptr;          // PSTAT_NRED doubles
   int64_t steps_recorded = 0;       // steps every chain has recorded so far (all inits)
@@ -109,9 +111,9 @@ int validate(const pstat_params *c, int ncases) {
 
 int trig_mode_from_env() {
   const char *e = getenv("PSTAT_TRIG");
-  if (!e) return 2;
+  if (!e) return 1;   // 1 = hardware v_sin/v_cos on turns (default), 0 = OCML sincosf (A/B)
   int v = atoi(e);
-  return (v >= 0 && v <= 2) ? v : 2;
+  return v == 0 ? 0 : 1;
 }
 
 int set_device(pstat_handle *h) {
@@ -211,6 +213,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   A.adj_lb = h->base.adj_lb; A.adj_ub = h->base.adj_ub; A.adj_scale = h->base.adj_scale;
   A.lanes = lanes;
   A.adaptive = (h->base.adj_scale != 1.0 && h->base.steps_per_adjust > 0) ? 1 : 0;  // mcmc_eap_chain.jl:302
+  A.ncases = ncases; A.seg_len = 0; A.nseg = 1; A.max_spins = 1 << 22;
   if ((int64_t)A.blocks_per_case * ncases > 0x7fffffffLL) {
     delete h;
     return fail(PSTAT_ERR_INVALID_ARG, "too many chains for one launch");
@@ -254,6 +257,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   const size_t nstate = h->bufs.size();
   CREATE_TRY(alloc(h, &S.ang_tmp, 2 * n * Cz * h->elem));
   CREATE_TRY(alloc(h, (void **)&h->d_cases, sizeof(CaseConst) * (size_t)ncases));
+  CREATE_TRY(alloc(h, (void **)&h->d_queue, sizeof(int) * sweep_queue_ints(h->args)));
   CREATE_TRY(alloc(h, (void **)&h->d_partial, sizeof(double) * reduce_scratch_doubles()));
   CREATE_TRY(alloc(h, (void **)&h->d_red, sizeof(double) * PSTAT_NRED));
   (void)nstate;
@@ -261,6 +265,13 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
                             hipMemcpyHostToDevice, h->stream));
   CREATE_HIP(launch_init(h->cfg, h->args, h->S, h->d_cases, h->base.phi_step, h->base.theta_step, h->stream));
   CREATE_HIP(hipStreamSynchronize(h->stream));  // h->cases must outlive the copy; also surfaces faults here
+  {
+    int lds = 0, bpc = 0;
+    hipDeviceProp_t prop;
+    CREATE_HIP(sweep_kernel_info(h->cfg, h->args, &lds, &bpc, nullptr));
+    CREATE_HIP(hipGetDeviceProperties(&prop, h->device));
+    h->slots = (bpc > 0 ? bpc : 1) * prop.multiProcessorCount;
+  }
 #undef CREATE_TRY
 #undef CREATE_HIP
   *out = h;
@@ -276,22 +287,61 @@ void pstat_destroy(pstat_handle *h) {
   delete h;
 }
 
+// Splits a launch of `nsteps` steps into time segments so that blocks*segments fills the resident
+// workgroup slots evenly (see sweep_kernel).  Returns segments per block.
+static int choose_segments(int64_t blocks, int64_t slots, int64_t nsteps) {
+  if (blocks <= slots || nsteps < 4000) return 1;
+  int best = 1;
+  double best_eff = 0;
+  for (int s = 1; s <= 12; ++s) {
+    if (nsteps / s < 2000) break;                 // keep fill/spill amortised
+    const double jobs = (double)blocks * s;
+    const double eff = jobs / (std::ceil(jobs / slots) * slots);   // busy fraction of the slots
+    if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+  }
+  return best;
+}
+
 int pstat_advance(pstat_handle *h, int64_t nsteps) {
   if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
   if (nsteps < 0) return fail(PSTAT_ERR_INVALID_ARG, "nsteps must be >= 0");
   if (nsteps == 0) return PSTAT_OK;
   int rc = set_device(h);
   if (rc) return rc;
-  // per-launch window counters are 32-bit
-  const int64_t max_seg = 1ll << 30;
+  const int64_t max_launch = 1ll << 30;  // per-launch step counters are 32-bit
+  const int64_t blocks = h->args.blocks_per_case * h->ncases;
+  const char *env = getenv("PSTAT_SEGMENTS");
+  if (const char *ms = getenv("PSTAT_MAX_SPINS")) h->args.max_spins = atoi(ms) > 0 ? atoi(ms) : h->args.max_spins;
   while (nsteps > 0) {
-    const int64_t seg = nsteps < max_seg ? nsteps : max_seg;
-    h->args.nsteps = seg;
+    const int64_t len = nsteps < max_launch ? nsteps : max_launch;
+    int nseg = env ? atoi(env) : choose_segments(blocks, h->slots, len);
+    if (nseg < 1) nseg = 1;
+    if (nseg > len) nseg = (int)len;
+    if (blocks * nseg > 0x3fffffffLL) nseg = 1;
+    h->args.nsteps = len;
     h->args.step0 = h->step_in_init;
-    HIP_TRY(launch_sweep(h->cfg, h->args, h->S, h->d_cases, h->ncases, h->stream));
-    h->step_in_init += seg;
-    h->steps_recorded += seg;
-    nsteps -= seg;
+    h->args.nseg = nseg;
+    h->args.seg_len = (len + nseg - 1) / nseg;
+    const int64_t jobs = blocks * nseg;
+    const unsigned grid = (unsigned)(jobs < h->slots ? jobs : h->slots);
+    HIP_TRY(launch_sweep(h->cfg, h->args, h->S, h->d_cases, h->d_queue, grid, h->stream));
+    h->step_in_init += len;
+    h->steps_recorded += len;
+    nsteps -= len;
+  }
+  return PSTAT_OK;
+}
+
+static int check_queue_error(pstat_handle *h) {
+  int flag = 0;
+  HIP_TRY(hipMemcpyAsync(&flag, h->d_queue + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (flag) {
+    int q[10] = {0};
+    (void)hipMemcpy(q, h->d_queue, sizeof q, hipMemcpyDeviceToHost);
+    return fail(PSTAT_ERR_HIP, "sweep kernel: job %d waited too long for its predecessor "
+                "(queue head %d, done[0..7] = %d %d %d %d %d %d %d %d)", flag - 1, q[0], q[2], q[3], q[4],
+                q[5], q[6], q[7], q[8], q[9]);
   }
   return PSTAT_OK;
 }
@@ -301,7 +351,7 @@ int pstat_sync(pstat_handle *h) {
   int rc = set_device(h);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
-  return PSTAT_OK;
+  return check_queue_error(h);
 }
 
 int pstat_reinit(pstat_handle *h, int32_t force_init) {
@@ -310,6 +360,7 @@ int pstat_reinit(pstat_handle *h, int32_t force_init) {
   if (rc) return rc;
   HIP_TRY(launch_reinit(h->cfg, h->args, h->S, h->d_cases, force_init, h->stream));
   h->step_in_init = 0;
+  h->cfg.lag = 1;  // from now on the sweep tracks the acceptor's stale-cache offset
   return PSTAT_OK;
 }
 
@@ -394,8 +445,10 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sum
     std::vector<unsigned char> tmp(2 * n * h->elem);
     HIP_TRY(hipMemcpy2D(tmp.data(), h->elem, (char *)h->S.ang + (size_t)chain * h->elem, C * h->elem,
                         h->elem, 2 * n, hipMemcpyDeviceToHost));
+    // f32 handles store angles in turns (pstat_kernels.hip, Ang<float>); the ABI speaks radians
     for (size_t i = 0; i < 2 * n; ++i)
-      angles[i] = h->elem == 8 ? ((double *)tmp.data())[i] : (double)((float *)tmp.data())[i];
+      angles[i] = h->elem == 8 ? ((double *)tmp.data())[i]
+                               : (double)((float *)tmp.data())[i] * 6.28318530717958647692;
   }
   if (sums) {
     double s[NSUMS];
@@ -444,7 +497,7 @@ int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes) {
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   CkptHeader hd{CKPT_MAGIC, h->base.n, h->S.C, h->ncases, h->steps_recorded, h->step_in_init,
-                h->base.precision, h->base.chain_type, h->base.energy_type, 0};
+                h->base.precision, h->base.chain_type, h->base.energy_type, h->cfg.lag};
   char *q = (char *)buf;
   std::memcpy(q, &hd, sizeof hd);
   q += sizeof hd;
@@ -477,6 +530,7 @@ int pstat_restore(pstat_handle *h, const void *buf, size_t bytes) {
   }
   h->steps_recorded = hd.steps_recorded;
   h->step_in_init = hd.step_in_init;
+  h->cfg.lag = hd.reserved;
   return PSTAT_OK;
 }
 

@@ -47,6 +47,10 @@ struct SweepArgs {
   double adj_lb, adj_ub, adj_scale;
   int32_t lanes;             // chains per workgroup (64, or fewer when n is too long for LDS)
   int32_t adaptive;          // adj_scale != 1 && steps_per_adjust > 0
+  int64_t ncases;
+  int64_t seg_len;           // steps per time segment (job) of this launch
+  int32_t nseg;              // segments per chain block in this launch
+  int32_t max_spins;         // bound on the predecessor wait (each spin sleeps ~2 us)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -93,12 +97,14 @@ struct Xoshiro128pp {
 // host-callable launchers implemented in pstat_kernels.hip; all asynchronous on `stream`
 struct LaunchCfg {
   int precision, chain_type, energy_type, do_flips, umbrella, has_fx, trig_mode;
+  int lag;  // a re-init has happened on this handle
 };
 hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                        const CaseConst *cases, double phi_step, double theta_step,
                        hipStream_t stream);
 hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
-                        const CaseConst *cases, int ncases, hipStream_t stream);
+                        const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream);
+size_t sweep_queue_ints(const SweepArgs &a);
 hipError_t launch_reinit(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                          const CaseConst *cases, int force_init, hipStream_t stream);
 // reduction of chains [c0, c1) into out[PSTAT_NRED]; partial = scratch of reduce_scratch_doubles()

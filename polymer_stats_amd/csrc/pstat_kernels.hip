@@ -123,6 +123,17 @@ __device__ __forceinline__ R pair_term(R rx, R ry, R rz, R mix, R miy, R miz, R 
 
 // ------------------------------------------------------------------------------------------ init
 
+// stored angle unit: radians for f64, turns for f32 (see Ang<> below)
+template <typename R> __host__ __device__ constexpr double ang_unit() {
+  return sizeof(R) == 4 ? 6.28318530717958647692 : 1.0;
+}
+template <typename R> __device__ __forceinline__ R store_phi(double u) {   // phi ~ U(0, 2pi)
+  return sizeof(R) == 4 ? (R)u : (R)(6.28318530717958647692 * u);
+}
+template <typename R> __device__ __forceinline__ R store_theta(double u) { // theta ~ U(0, pi)
+  return sizeof(R) == 4 ? (R)(0.5 * u) : (R)(3.14159265358979323846 * u);
+}
+
 // EAPChain(pargs), inc/eap_chain.jl:60-135: all phi draws, then all theta draws; then r, p, U.
 // One thread per chain; angles are rounded to the storage type R before anything is derived.
 template <typename R>
@@ -135,13 +146,13 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
   R *th = (R *)S.ang, *ph = (R *)S.ang + A.n * S.C;
   Xoshiro128pp g;
   g.seed(cc.seed, cc.chain_id0 + (uint64_t)local);
-  for (int64_t i = 0; i < A.n; ++i) ph[i * S.C + c] = (R)(6.28318530717958647692 * u01<double>(g.next()));
-  for (int64_t i = 0; i < A.n; ++i) th[i * S.C + c] = (R)(3.14159265358979323846 * u01<double>(g.next()));
+  for (int64_t i = 0; i < A.n; ++i) ph[i * S.C + c] = store_phi<R>(u01<double>(g.next()));
+  for (int64_t i = 0; i < A.n; ++i) th[i * S.C + c] = store_theta<R>(u01<double>(g.next()));
 
   double r[3] = {0, 0, 0}, p[3] = {0, 0, 0}, usum = 0, upair = 0, omega = 0;
   double pnx = 0, pny = 0, pnz = 0, pmx = 0, pmy = 0, pmz = 0;
   for (int64_t i = 0; i < A.n; ++i) {
-    double t = (double)th[i * S.C + c], f = (double)ph[i * S.C + c];
+    double t = (double)th[i * S.C + c] * ang_unit<R>(), f = (double)ph[i * S.C + c] * ang_unit<R>();
     double st = sin(t), ct = cos(t), sp = sin(f), cp = cos(f);
     double nx = cp * st, ny = sp * st, nz = ct, mx, my, mz;
     if (chain_type == PSTAT_DIELECTRIC)
@@ -174,36 +185,80 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
 
 // ------------------------------------------------------------------------------------------ sweep
 
-template <typename R, int CT, int EN, bool FX, bool FLIPS, int TRIG>
-__global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
-                                                   const CaseConst *__restrict__ cases) {
-  using R2 = typename Vec2<R>::type;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  R2 *ang = reinterpret_cast<R2 *>(smem);  // [n][lanes] : .x = theta, .y = phi
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-  const int lane = threadIdx.x;
+// Angle representation per arithmetic type.
+//   f64: radians, exactly the reference's variables (bit-reproduces the CPU oracle).
+//   f32: TURNS (theta/2pi in [0, 1/2], phi/2pi in [0, 1)).  gfx950's v_sin_f32/v_cos_f32 take turns
+//        and are accurate to 1.3e-7 absolute there (tools/ubench), phi wraps with one v_fract, and
+//        no range reduction or 1/2pi pre-scale is ever needed.
+template <typename R, int TRIG> struct Ang;
+template <int TRIG> struct Ang<double, TRIG> {
+  static constexpr double theta_max = 3.14159265358979323846;
+  static constexpr double unit = 1.0;  // radians per stored unit
+  static __device__ __forceinline__ void sc(double x, double *s, double *c) { sincos(x, s, c); }
+  static __device__ __forceinline__ double wrap(double x) { return x; }  // phi random-walks, eap_chain.jl:232
+};
+template <int TRIG> struct Ang<float, TRIG> {
+  static constexpr float theta_max = 0.5f;
+  static constexpr double unit = 6.28318530717958647692;
+  static __device__ __forceinline__ void sc(float x, float *s, float *c) {
+    if constexpr (TRIG == 0) {
+      sincosf(x * 6.28318548202514648f, s, c);  // OCML reference path (A/B only)
+    } else {
+      *s = __builtin_amdgcn_sinf(x);
+      *c = __builtin_amdgcn_cosf(x);
+    }
+  }
+  static __device__ __forceinline__ float wrap(float x) { return __builtin_amdgcn_fractf(x); }
+};
+
+struct Draw {  // raw words of one step's proposal, mcmc_eap_chain.jl:277-280,287
+  uint32_t idx, wphi, wth, weps, wflip;
+};
+
+template <bool RARE>
+__device__ __forceinline__ Draw draw_step(Xoshiro128pp &g, uint32_t n, bool flips) {
+  Draw d;
+  d.idx = __umulhi(g.next(), n);
+  d.wphi = g.next();
+  d.wflip = 0;
+  if constexpr (RARE) {
+    if (flips) d.wflip = g.next();
+  }
+  d.wth = g.next();
+  d.weps = g.next();
+  return d;
+}
+
+struct SweepRare {  // wave-uniform switches of the rarely used options (RARE instantiations only)
+  int flips;        // --do-flips
+  int lag;          // a re-init happened: the acceptor's cached log-pi may be offset (see reinit_kernel)
+};
+
+// One time-segment of one chain block: fill LDS/registers from HBM, run `nsteps` steps, spill.
+template <typename R, int CT, int EN, bool FX, bool RARE, int TRIG>
+__device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &S, const CaseConst &cc,
+                                            const SweepRare rare, unsigned char *smem, const int lane,
+                                            const int64_t c, int64_t step, int64_t remaining) {
+  using R2 = typename Vec2<R>::type;
+  using AG = Ang<R, TRIG>;
+  R2 *ang = reinterpret_cast<R2 *>(smem);  // [n][lanes] : .x = theta, .y = phi
   const int lanes = A.lanes;
-  const int64_t icase = blockIdx.x / A.blocks_per_case;
-  const int64_t local = (int64_t)(blockIdx.x % A.blocks_per_case) * lanes + lane;
-  // lanes own disjoint LDS columns and never exchange data, so idle lanes can simply leave
-  if (lane >= lanes || local >= A.chains_per_case) return;
-  const int64_t c = icase * A.chains_per_case + local;
   const int64_t C = S.C;
   const int n = (int)A.n;
 
-  // ---- per-case scalars (wave-uniform => SGPRs)
-  const CaseConst cc = cases[icase];
-  const R kT = (R)cc.kT, Fz = (R)cc.Fz, Fx = (R)cc.Fx, b = (R)cc.b;
-  (void)kT; (void)Fx;
+  // ---- per-case scalars (wave-uniform => SGPRs).  Step sizes are kept in radians (f64) for the
+  // adaptation logic and converted to the storage unit when they change.
+  const R Fz = (R)cc.Fz, Fx = (R)cc.Fx, b = (R)cc.b, kT = (R)cc.kT;
   const R a_or_mu = (CT == PSTAT_DIELECTRIC) ? (R)((cc.K1 - cc.K2) * cc.E0) : (R)cc.mu;
   const R k2e = (R)(cc.K2 * cc.E0);
   const R mhalfE0 = (R)(-0.5 * cc.E0);
-  const R invkT = (R)(1.0 / cc.kT);
-  (void)invkT;
   const R hb = (R)(-cc.b / 2);
-  (void)hb;
+  const R nbeta_log2e = (R)(-1.4426950408889634 / cc.kT);  // exp(-dU/kT) = exp2(dU * this)
+  (void)Fx; (void)kT; (void)hb; (void)nbeta_log2e;
 
-  // ---- fill: angles HBM -> LDS (coalesced over lanes), scalars HBM -> registers
+  // ---- fill
   {
     const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
     for (int i = 0; i < n; ++i) {
@@ -216,57 +271,64 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
   Xoshiro128pp g;
   g.s0 = S.rng[0 * C + c]; g.s1 = S.rng[1 * C + c]; g.s2 = S.rng[2 * C + c]; g.s3 = S.rng[3 * C + c];
   double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
-  R phistep = (R)phistep_d, thstep = (R)thstep_d;
-  int nacc = S.win[0 * C + c], natt = S.win[1 * C + c];
-  int nacc_seg = 0;
-  R rx = (R)S.obs[OBS_R1 * C + c], ry = (R)S.obs[OBS_R2 * C + c], rz = (R)S.obs[OBS_R3 * C + c];
-  R px = (R)S.obs[OBS_P1 * C + c], py = (R)S.obs[OBS_P2 * C + c], pz = (R)S.obs[OBS_P3 * C + c];
-  R U = (R)S.obs[OBS_U * C + c], usum = (R)S.obs[OBS_USUM * C + c];
-  R lag = (R)S.lag[c];
+  R phistep = (R)(phistep_d / AG::unit), thstep = (R)(thstep_d / AG::unit);
+  int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
+  int nacc_seg = 0, steps_seg = 0;
+  // observables O = (rx, ry | rz, px | py, pz | U, unused) as four 2-vectors (packed f32 math)
+  R O[8];
+  O[0] = (R)S.obs[OBS_R1 * C + c]; O[1] = (R)S.obs[OBS_R2 * C + c]; O[2] = (R)S.obs[OBS_R3 * C + c];
+  O[3] = (R)S.obs[OBS_P1 * C + c]; O[4] = (R)S.obs[OBS_P2 * C + c]; O[5] = (R)S.obs[OBS_P3 * C + c];
+  O[6] = (R)S.obs[OBS_U * C + c]; O[7] = 0;
+  R usum = (R)S.obs[OBS_USUM * C + c];
+  R lag = RARE ? (R)S.lag[c] : (R)0;
   double sums[NSUMS];
 #pragma unroll
   for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
 
-  int64_t step = A.step0;
-  int64_t remaining = A.nsteps;
   const int64_t spa = A.steps_per_adjust;
+  int64_t to_adj = A.adaptive ? spa - (step % spa) : 0;
   constexpr int FLUSH = 128;  // f32 partial sums are folded into the f64 sums this often
+  const bool flips = RARE && rare.flips;
+
+  // software pipeline: the draws and the LDS row of the NEXT step are fetched while the current
+  // step computes; if both steps hit the same monomer and the current one is accepted, the
+  // prefetched row is replaced by the freshly accepted angles.
+  Draw d = draw_step<RARE>(g, (uint32_t)n, flips);
+  R2 a0 = ang[d.idx * lanes + lane];
 
   while (remaining > 0) {
     int64_t chunk = remaining < FLUSH ? remaining : FLUSH;
-    if (A.adaptive) {
-      int64_t to_adj = spa - (step % spa);
-      if (to_adj < chunk) chunk = to_adj;
-    }
-    R acc[NSUMS];
+    if (A.adaptive && to_adj < chunk) chunk = to_adj;
+    R acc1[8], acc2[8];
 #pragma unroll
-    for (int q = 0; q < NSUMS; ++q) acc[q] = 0;
+    for (int q = 0; q < 8; ++q) { acc1[q] = 0; acc2[q] = 0; }
 
     for (int k = 0; k < (int)chunk; ++k) {
+      const bool more = remaining - k > 1;  // wave-uniform
+      Draw dn = d;
+      R2 an = a0;
+      if (more) {
+        dn = draw_step<RARE>(g, (uint32_t)n, flips);
+        an = ang[dn.idx * lanes + lane];
+      }
       // ---- proposal, mcmc_eap_chain.jl:277-280
-      const uint32_t idx = __umulhi(g.next(), (uint32_t)n);
-      const R dphi = phistep * sym11<R>(g.next());
-      const R2 a0 = ang[idx * lanes + lane];
       const R th0 = a0.x, ph0 = a0.y;
+      const R dphi = phistep * sym11<R>(d.wphi);
       R flip = 0;
-      if constexpr (FLIPS) {
-        if (g.next() >> 31) flip = K<R>::pi - 2 * th0;
+      if constexpr (RARE) {
+        if (flips && (d.wflip >> 31)) flip = AG::theta_max - 2 * th0;
       }
-      const R dth = flip + thstep * sym11<R>(g.next());
-      const R eps = u01<R>(g.next());
+      const R dth = flip + thstep * sym11<R>(d.wth);
+      const R eps = u01<R>(d.weps);
 
-      // ---- move!, inc/eap_chain.jl:232-245 (trial values only; committed on acceptance)
-      R ph1 = ph0 + dphi;
-      if constexpr (sizeof(R) == 4) {  // f32 only: keep |phi| small so its ulp stays ~2e-7
-        ph1 = ph1 >= K<R>::two_pi ? ph1 - K<R>::two_pi : ph1;
-        ph1 = ph1 < 0 ? ph1 + K<R>::two_pi : ph1;
-      }
-      const R th1 = fmin(K<R>::pi, fmax((R)0, th0 + dth));
+      // ---- move!, inc/eap_chain.jl:232-245 (trial values; committed by selects below)
+      const R ph1 = AG::wrap(ph0 + dphi);
+      const R th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
       R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
-      sincos_r<TRIG>(th0, &st0, &ct0);
-      sincos_r<TRIG>(ph0, &sp0, &cp0);
-      sincos_r<TRIG>(th1, &st1, &ct1);
-      sincos_r<TRIG>(ph1, &sp1, &cp1);
+      AG::sc(th0, &st0, &ct0);
+      AG::sc(th1, &st1, &ct1);
+      AG::sc(ph0, &sp0, &cp0);
+      AG::sc(ph1, &sp1, &cp1);
       const R n0x = cp0 * st0, n0y = sp0 * st0, n0z = ct0;
       const R n1x = cp1 * st1, n1y = sp1 * st1, n1z = ct1;
       R m0x, m0y, m0z, m1x, m1y, m1z;
@@ -275,18 +337,20 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
 
       // ---- energy difference, inc/energy.jl:7-9,20-23; inc/eap_chain.jl:53
       const R du = mhalfE0 * (m1z - m0z);
-      const R drx = b * (n1x - n0x), dry = b * (n1y - n0y), drz = b * (n1z - n0z);
+      R dO[8];
+      dO[0] = b * (n1x - n0x); dO[1] = b * (n1y - n0y); dO[2] = b * (n1z - n0z);
+      dO[3] = m1x - m0x; dO[4] = m1y - m0y; dO[5] = m1z - m0z;
       R dpair = 0;
       if constexpr (EN == PSTAT_ISING) {
         R e0 = 0, e1 = 0;
 #pragma unroll
         for (int side = -1; side <= 1; side += 2) {
-          const int j = (int)idx + side;
+          const int j = (int)d.idx + side;
           if (j >= 0 && j < n) {
             const R2 aj = ang[j * lanes + lane];
             R sj, cj, spj, cpj, mjx, mjy, mjz;
-            sincos_r<TRIG>(aj.x, &sj, &cj);
-            sincos_r<TRIG>(aj.y, &spj, &cpj);
+            AG::sc(aj.x, &sj, &cj);
+            AG::sc(aj.y, &spj, &cpj);
             const R njx = cpj * sj, njy = spj * sj, njz = cj;
             dipole<R, CT>(a_or_mu, k2e, njx, njy, njz, mjx, mjy, mjz);
             e0 += pair_term<R>(hb * (n0x + njx), hb * (n0y + njy), hb * (n0z + njz),
@@ -298,8 +362,9 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
         dpair = e1 - e0;
       }
       R dU;
-      if constexpr (FX) dU = du + dpair - (Fx * drx + Fz * drz);
-      else              dU = du + dpair - (Fz * drz);
+      if constexpr (FX) dU = du + dpair - (Fx * dO[0] + Fz * dO[2]);
+      else              dU = du + dpair - (Fz * dO[2]);
+      dO[6] = dU; dO[7] = 0;
 
       // ---- Metropolis, inc/acceptance.jl:18-39.  pi ~ exp(-U/kT) * prod sin(theta)
       bool ok;
@@ -307,48 +372,63 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
         const R delta = -dU / kT + log(st1 / st0) - lag;
         ok = (delta >= 0) || (eps < exp(delta));
       } else {
-        // same test with the log folded away: eps < exp(-dU/kT) * sin(th1)/sin(th0)
-        ok = eps * st0 < st1 * exp_r(-dU * invkT - lag);
+        // same test with the logarithm folded away: eps * sin(th0) < sin(th1) * exp(-dU/kT - lag)
+        R e;
+        if constexpr (RARE) e = __builtin_amdgcn_exp2f((R)1.44269504f * (-lag) + dU * nbeta_log2e);
+        else                e = __builtin_amdgcn_exp2f(dU * nbeta_log2e);
+        ok = eps * st0 < st1 * e;
       }
-      if (ok) {
-        R2 a1; a1.x = th1; a1.y = ph1;
-        ang[idx * lanes + lane] = a1;
-        rx += drx; ry += dry; rz += drz;
-        px += m1x - m0x; py += m1y - m0y; pz += m1z - m0z;
-        usum += du; U += dU;
-        lag = 0;
-        ++nacc; ++nacc_seg;
+
+      // ---- commit (branch-free): angles, observables, counters
+      R2 a1; a1.x = ok ? th1 : th0; a1.y = ok ? ph1 : ph0;
+      ang[d.idx * lanes + lane] = a1;
+      const R m = ok ? (R)1 : (R)0;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) O[q] = fma_r(m, dO[q], O[q]);
+      usum = fma_r(m, du, usum);
+      if constexpr (RARE) lag = ok ? (R)0 : lag;
+      nacc_seg += ok ? 1 : 0;
+      if (more) {  // forward the accepted angles into the prefetched row if it is the same monomer
+        const bool same = dn.idx == d.idx;
+        an.x = same ? a1.x : an.x;
+        an.y = same ? a1.y : an.y;
       }
-      ++natt;
 
       // ---- record! x 8, mcmc_eap_chain.jl:327-328 (every step, accepted or not)
-      acc[S_R1] += rx; acc[S_R2] += ry; acc[S_R3] += rz;
-      acc[S_R1SQ] = fma_r(rx, rx, acc[S_R1SQ]); acc[S_R2SQ] = fma_r(ry, ry, acc[S_R2SQ]);
-      acc[S_R3SQ] = fma_r(rz, rz, acc[S_R3SQ]);
-      acc[S_P1] += px; acc[S_P2] += py; acc[S_P3] += pz;
-      acc[S_P1SQ] = fma_r(px, px, acc[S_P1SQ]); acc[S_P2SQ] = fma_r(py, py, acc[S_P2SQ]);
-      acc[S_P3SQ] = fma_r(pz, pz, acc[S_P3SQ]);
-      acc[S_U] += U; acc[S_USQ] = fma_r(U, U, acc[S_USQ]);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { acc1[q] += O[q]; acc2[q] = fma_r(O[q], O[q], acc2[q]); }
+      d = dn;
+      a0 = an;
     }
 
-#pragma unroll
-    for (int q = 0; q < NSUMS; ++q) sums[q] += (double)acc[q];
+    sums[S_R1] += (double)acc1[0]; sums[S_R2] += (double)acc1[1]; sums[S_R3] += (double)acc1[2];
+    sums[S_P1] += (double)acc1[3]; sums[S_P2] += (double)acc1[4]; sums[S_P3] += (double)acc1[5];
+    sums[S_U] += (double)acc1[6];
+    sums[S_R1SQ] += (double)acc2[0]; sums[S_R2SQ] += (double)acc2[1]; sums[S_R3SQ] += (double)acc2[2];
+    sums[S_P1SQ] += (double)acc2[3]; sums[S_P2SQ] += (double)acc2[4]; sums[S_P3SQ] += (double)acc2[5];
+    sums[S_USQ] += (double)acc2[6];
     step += chunk;
     remaining -= chunk;
+    steps_seg += (int)chunk;
 
     // ---- step-size adaptation, mcmc_eap_chain.jl:301-322 (per chain, in f64 like the reference)
-    if (A.adaptive && step % spa == 0) {
-      const double ratio = (double)nacc / (double)natt;
-      if (ratio > A.adj_ub && phistep_d != K<double>::pi && thstep_d != K<double>::half_pi) {
-        nacc = 0; natt = 0;
-        phistep_d = fmin(K<double>::pi, phistep_d * A.adj_scale);
-        thstep_d = fmin(K<double>::half_pi, thstep_d * A.adj_scale);
-      } else if (ratio < A.adj_lb) {
-        nacc = 0; natt = 0;
-        phistep_d /= A.adj_scale;
-        thstep_d /= A.adj_scale;
+    if (A.adaptive) {
+      to_adj -= chunk;
+      if (to_adj == 0) {
+        to_adj = spa;
+        const int nacc = nacc_off + nacc_seg, natt = natt_off + steps_seg;
+        const double ratio = (double)nacc / (double)natt;
+        if (ratio > A.adj_ub && phistep_d != K<double>::pi && thstep_d != K<double>::half_pi) {
+          nacc_off = -nacc_seg; natt_off = -steps_seg;
+          phistep_d = fmin(K<double>::pi, phistep_d * A.adj_scale);
+          thstep_d = fmin(K<double>::half_pi, thstep_d * A.adj_scale);
+        } else if (ratio < A.adj_lb) {
+          nacc_off = -nacc_seg; natt_off = -steps_seg;
+          phistep_d /= A.adj_scale;
+          thstep_d /= A.adj_scale;
+        }
+        phistep = (R)(phistep_d / AG::unit); thstep = (R)(thstep_d / AG::unit);
       }
-      phistep = (R)phistep_d; thstep = (R)thstep_d;
     }
   }
 
@@ -363,14 +443,74 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
   }
   S.rng[0 * C + c] = g.s0; S.rng[1 * C + c] = g.s1; S.rng[2 * C + c] = g.s2; S.rng[3 * C + c] = g.s3;
   S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
-  S.win[0 * C + c] = nacc; S.win[1 * C + c] = natt;
+  S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
   S.nacc_total[c] += nacc_seg;
-  S.obs[OBS_R1 * C + c] = rx; S.obs[OBS_R2 * C + c] = ry; S.obs[OBS_R3 * C + c] = rz;
-  S.obs[OBS_P1 * C + c] = px; S.obs[OBS_P2 * C + c] = py; S.obs[OBS_P3 * C + c] = pz;
-  S.obs[OBS_U * C + c] = U; S.obs[OBS_USUM * C + c] = usum;
-  S.lag[c] = lag;
+  S.obs[OBS_R1 * C + c] = O[0]; S.obs[OBS_R2 * C + c] = O[1]; S.obs[OBS_R3 * C + c] = O[2];
+  S.obs[OBS_P1 * C + c] = O[3]; S.obs[OBS_P2 * C + c] = O[4]; S.obs[OBS_P3 * C + c] = O[5];
+  S.obs[OBS_U * C + c] = O[6]; S.obs[OBS_USUM * C + c] = usum;
+  if constexpr (RARE) S.lag[c] = lag;
 #pragma unroll
   for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
+}
+
+// Persistent sweep kernel.  A job = (chain block, time segment); jobs are handed out in segment-major
+// order from one atomic counter, so all LDS-limited workgroup slots of the chip stay busy even when
+// the number of chain blocks is not a multiple of the slots (e.g. 1024 blocks on 768 slots at
+// n = 100).  Segment s of a block may start only after segment s-1 of the same block has been
+// spilled: a per-block counter, published with an agent-scope release and awaited with a relaxed
+// poll + one agent-scope acquire (placement-independent; cdna_hip_programming.md Guideline 16).
+// Deadlock-free for any residency: a job's predecessor was handed out earlier, to a workgroup that is
+// running and that itself only ever waits on still earlier jobs.
+template <typename R, int CT, int EN, bool FX, bool RARE, int TRIG>
+__global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
+                                                   const CaseConst *__restrict__ cases,
+                                                   SweepRare rare, int *__restrict__ queue) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int nblocks = (int)(A.blocks_per_case * A.ncases);
+  const int njobs = nblocks * A.nseg;
+  int *head = queue, *error = queue + 1, *done = queue + 2;
+  bool failed = false;
+  while (!failed) {
+    int job = 0;
+    if (lane == 0) job = atomicAdd(head, 1);
+    job = __builtin_amdgcn_readfirstlane(job);
+    if (job >= njobs) break;
+    const int blk = job % nblocks, seg = job / nblocks;
+    if (seg > 0) {
+      int spins = 0;
+      for (;;) {
+        const int have = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load(&done[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (have >= seg) break;
+        if (++spins > A.max_spins) { failed = true; break; }
+        __builtin_amdgcn_s_sleep(64);
+      }
+      if (failed) {  // a predecessor never finished: flag it and stop taking jobs
+        if (lane == 0) atomicExch(error, 1 + job);
+        break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    const int64_t icase = blk / A.blocks_per_case;
+    const int64_t local = (int64_t)(blk % A.blocks_per_case) * A.lanes + lane;
+    const int64_t first = (int64_t)seg * A.seg_len;
+    const int64_t left = A.nsteps - first;
+    const int64_t len = left < A.seg_len ? left : A.seg_len;
+    // lanes own disjoint LDS columns and never exchange data: idle lanes just skip the body
+    if (len > 0 && lane < A.lanes && local < A.chains_per_case) {
+      const CaseConst cc = cases[icase];
+      run_segment<R, CT, EN, FX, RARE, TRIG>(A, S, cc, rare, smem, lane,
+                                             icase * A.chains_per_case + local, A.step0 + first, len);
+    }
+    if (A.nseg > 1) {
+      // publish: this wave's spill stores are complete and written back before the counter moves
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&done[blk], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ reduce
@@ -459,13 +599,13 @@ __global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restri
   R *nth = (R *)S.ang_tmp, *nph = (R *)S.ang_tmp + n * C;
   Xoshiro128pp g;
   g.s0 = S.rng[0 * C + c]; g.s1 = S.rng[1 * C + c]; g.s2 = S.rng[2 * C + c]; g.s3 = S.rng[3 * C + c];
-  for (int64_t i = 0; i < n; ++i) nph[i * C + c] = (R)(6.28318530717958647692 * u01<double>(g.next()));
-  for (int64_t i = 0; i < n; ++i) nth[i * C + c] = (R)(3.14159265358979323846 * u01<double>(g.next()));
+  for (int64_t i = 0; i < n; ++i) nph[i * C + c] = store_phi<R>(u01<double>(g.next()));
+  for (int64_t i = 0; i < n; ++i) nth[i * C + c] = store_theta<R>(u01<double>(g.next()));
 
   double r[3] = {0, 0, 0}, p[3] = {0, 0, 0}, usum = 0, upair = 0, prod_new = 1.0, prod_old = 1.0;
   double pnx = 0, pny = 0, pnz = 0, pmx = 0, pmy = 0, pmz = 0;
   for (int64_t i = 0; i < n; ++i) {
-    double t = (double)nth[i * C + c], f = (double)nph[i * C + c];
+    double t = (double)nth[i * C + c] * ang_unit<R>(), f = (double)nph[i * C + c] * ang_unit<R>();
     double st = sin(t), ct = cos(t), sp = sin(f), cp = cos(f);
     double nx = cp * st, ny = sp * st, nz = ct, mx, my, mz;
     if (chain_type == PSTAT_DIELECTRIC)
@@ -476,7 +616,7 @@ __global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restri
     p[0] += mx; p[1] += my; p[2] += mz;
     usum += -0.5 * cc.E0 * mz;
     prod_new *= st;
-    prod_old *= sin((double)th[i * C + c]);
+    prod_old *= sin((double)th[i * C + c] * ang_unit<R>());
     if (energy_type == PSTAT_ISING && i > 0) {
       double h = -cc.b / 2;
       upair += pair_term<double>(h * (pnx + nx), h * (pny + ny), h * (pnz + nz), pmx, pmy, pmz, mx, my, mz);
@@ -513,26 +653,23 @@ int choose_lanes(int precision, int64_t n, int energy_type) {
   return 0;
 }
 
-using SweepFn = void (*)(SweepArgs, DevState, const CaseConst *);
+using SweepFn = void (*)(SweepArgs, DevState, const CaseConst *, SweepRare, int *);
 
-template <typename R, int CT, int EN, bool FX, bool FLIPS>
+template <typename R, int CT, int EN, bool FX, bool RARE>
 static SweepFn pick_trig(int trig) {
   if constexpr (sizeof(R) == 8) {
-    return sweep_kernel<R, CT, EN, FX, FLIPS, 0>;
+    return sweep_kernel<R, CT, EN, FX, RARE, 0>;
   } else {
-    switch (trig) {
-      case 1: return sweep_kernel<R, CT, EN, FX, FLIPS, 1>;
-      case 2: return sweep_kernel<R, CT, EN, FX, FLIPS, 2>;
-      default: return sweep_kernel<R, CT, EN, FX, FLIPS, 0>;
-    }
+    return trig == 0 ? sweep_kernel<R, CT, EN, FX, RARE, 0> : sweep_kernel<R, CT, EN, FX, RARE, 1>;
   }
 }
 template <typename R, int CT, int EN>
 static SweepFn pick_flags(const LaunchCfg &cfg) {
-  if (cfg.has_fx) return cfg.do_flips ? pick_trig<R, CT, EN, true, true>(cfg.trig_mode)
-                                      : pick_trig<R, CT, EN, true, false>(cfg.trig_mode);
-  return cfg.do_flips ? pick_trig<R, CT, EN, false, true>(cfg.trig_mode)
-                      : pick_trig<R, CT, EN, false, false>(cfg.trig_mode);
+  const bool rare = cfg.do_flips || cfg.lag || cfg.umbrella;
+  if (cfg.has_fx) return rare ? pick_trig<R, CT, EN, true, true>(cfg.trig_mode)
+                              : pick_trig<R, CT, EN, true, false>(cfg.trig_mode);
+  return rare ? pick_trig<R, CT, EN, false, true>(cfg.trig_mode)
+              : pick_trig<R, CT, EN, false, false>(cfg.trig_mode);
 }
 template <typename R>
 static SweepFn pick_model(const LaunchCfg &cfg) {
@@ -566,14 +703,19 @@ hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_
   return hipSuccess;
 }
 
+// queue layout: [0] job counter, [1] error flag, [2 ..] per-block "segments done"
+size_t sweep_queue_ints(const SweepArgs &a) { return 2 + (size_t)(a.blocks_per_case * a.ncases); }
+
 hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
-                        const CaseConst *cases, int ncases, hipStream_t stream) {
+                        const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream) {
   SweepFn fn = pick_sweep(cfg);
   const int lds = sweep_lds_bytes(cfg, a);
   hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  const unsigned grid = (unsigned)(a.blocks_per_case * ncases);
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a, s, cases);
+  e = hipMemsetAsync(queue, 0, sizeof(int) * sweep_queue_ints(a), stream);
+  if (e != hipSuccess) return e;
+  SweepRare rare{cfg.do_flips, cfg.lag};
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a, s, cases, rare, queue);
   return hipGetLastError();
 }
 

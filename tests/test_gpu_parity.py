@@ -78,13 +78,39 @@ def test_segments_checkpoint_and_sharding_invariance(ps, oracle):
         for k in ("theta", "phi", "rng"):
             assert np.array_equal(a[k], b[k]), k
         assert a["nacc_total"] == b["nacc_total"]
-        np.testing.assert_allclose(a["sums"], b["sums"], rtol=1e-5)
+        np.testing.assert_allclose(a["sums"], b["sums"], rtol=1e-5, atol=1e-6 * 5000 * 40)
     _, shard = both(5000, num_chains=32, chain_id0=32, precision=ps.F32, n=40, E0=1.0, Fz=0.5, seed=21)
     with ps.Ensemble(pp) as whole, ps.Ensemble(shard) as half:
         whole.advance(5000)
         half.advance(5000)
         a, b = whole.chain_state(32 + 5), half.chain_state(5)
         assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["phi"], b["phi"])
+
+
+def test_time_segments_match_single_launch(ps, monkeypatch):
+    """The persistent sweep kernel splits a launch into (chain block, time segment) jobs.  With every
+    job co-resident (64 blocks x 3 segments) later segments really wait on their predecessors; the
+    result must be bit-identical to the unsegmented launch."""
+    pp = ps.default_params(num_chains=4096, precision=ps.F32, n=40, E0=1.0, Fz=0.5, seed=6)
+    monkeypatch.setenv("PSTAT_MAX_SPINS", str(1 << 19))     # fail within ~1 s instead of hanging
+    states = {}
+    for nseg in ("1", "3", "7"):
+        monkeypatch.setenv("PSTAT_SEGMENTS", nseg)
+        with ps.Ensemble(pp) as e:
+            e.advance(9000)
+            e.sync()
+            states[nseg] = [e.chain_state(c) for c in (0, 63, 64, 1000, 4095)]
+            avg, _ = e.rolling()
+            states[nseg + "avg"] = avg
+    for nseg in ("3", "7"):
+        for a, b in zip(states["1"], states[nseg]):
+            for k in ("theta", "phi", "rng"):
+                assert np.array_equal(a[k], b[k]), (nseg, k)
+            assert a["nacc_total"] == b["nacc_total"] and a["phi_step"] == b["phi_step"]
+            # f32 block partials are flushed at different points -> rounding-level differences,
+            # measured against the size of the summed terms (sum r1 cancels to ~0)
+            np.testing.assert_allclose(a["sums"], b["sums"], rtol=1e-5, atol=1e-6 * 9000 * 40)
+        np.testing.assert_allclose(states["1avg"], states[nseg + "avg"], rtol=1e-6, atol=1e-5)
 
 
 def test_batched_cases_match_single_case_handles(ps):
@@ -102,7 +128,7 @@ def test_batched_cases_match_single_case_handles(ps):
                 np.testing.assert_allclose(avg_b, avg_s, rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("trig", ["0", "1", "2"])
+@pytest.mark.parametrize("trig", ["0", "1"])
 def test_f32_statistical_parity_config2(ps, oracle, golden, trig, monkeypatch):
     """BASELINE configs[1] at Fz=1: n=100 dielectric.  f32 kernel vs CPU oracle under the SAME
     protocol (no burn-in, adaptation on): pooled means agree within 4 sigma."""
