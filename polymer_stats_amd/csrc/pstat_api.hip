@@ -84,8 +84,9 @@ int validate(const pstat_params *c, int ncases) {
     return fail(PSTAT_ERR_INVALID_ARG, "chain-type is not understood.");       // eap_chain.jl:86
   if (b.energy_type < PSTAT_NONINTERACTING || b.energy_type > PSTAT_ISING)
     return fail(PSTAT_ERR_INVALID_ARG, "energy-type is not understood.");      // eap_chain.jl:104
-  if (b.energy_type == PSTAT_INTERACTING)
-    return fail(PSTAT_ERR_UNSUPPORTED, "energy-type 'interacting' has no device kernel yet");
+  if (b.energy_type == PSTAT_INTERACTING && b.n > 64)
+    return fail(PSTAT_ERR_UNSUPPORTED, "energy-type 'interacting' runs one chain per 64-lane wavefront: "
+                "num-monomers must be <= 64 (got %lld)", (long long)b.n);
   if (b.umbrella)
     return fail(PSTAT_ERR_UNSUPPORTED, "umbrella sampling has no device kernel yet");
   if (b.precision != PSTAT_F32 && b.precision != PSTAT_F64)
@@ -198,7 +199,8 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   h->cfg = {h->base.precision, h->base.chain_type, h->base.energy_type, h->base.do_flips ? 1 : 0,
             h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, trig_mode_from_env()};
 
-  const int lanes = choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
+  const bool inter = h->base.energy_type == PSTAT_INTERACTING;
+  const int lanes = inter ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
   if (lanes == 0) {
     delete h;
     return fail(PSTAT_ERR_UNSUPPORTED, "num-monomers = %lld does not fit the 160 KiB LDS of a CU",
@@ -261,11 +263,16 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_TRY(alloc(h, (void **)&h->d_partial, sizeof(double) * reduce_scratch_doubles()));
   CREATE_TRY(alloc(h, (void **)&h->d_red, sizeof(double) * PSTAT_NRED));
   (void)nstate;
+  CREATE_HIP(hipMemsetAsync(h->d_queue, 0, sizeof(int) * sweep_queue_ints(h->args), h->stream));
   CREATE_HIP(hipMemcpyAsync(h->d_cases, h->cases.data(), sizeof(CaseConst) * (size_t)ncases,
                             hipMemcpyHostToDevice, h->stream));
   CREATE_HIP(launch_init(h->cfg, h->args, h->S, h->d_cases, h->base.phi_step, h->base.theta_step, h->stream));
+  if (inter) {  // a zero-step launch derives r, p, U (with the pair energy) from the fresh angles
+    h->args.nsteps = 0; h->args.step0 = 0;
+    CREATE_HIP(launch_interacting(h->cfg, h->args, h->S, h->d_cases, h->stream));
+  }
   CREATE_HIP(hipStreamSynchronize(h->stream));  // h->cases must outlive the copy; also surfaces faults here
-  {
+  if (!inter) {
     int lds = 0, bpc = 0;
     hipDeviceProp_t prop;
     CREATE_HIP(sweep_kernel_info(h->cfg, h->args, &lds, &bpc, nullptr));
@@ -309,6 +316,18 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
   int rc = set_device(h);
   if (rc) return rc;
   const int64_t max_launch = 1ll << 30;  // per-launch step counters are 32-bit
+  if (h->base.energy_type == PSTAT_INTERACTING) {
+    while (nsteps > 0) {
+      const int64_t len = nsteps < max_launch ? nsteps : max_launch;
+      h->args.nsteps = len;
+      h->args.step0 = h->step_in_init;
+      HIP_TRY(launch_interacting(h->cfg, h->args, h->S, h->d_cases, h->stream));
+      h->step_in_init += len;
+      h->steps_recorded += len;
+      nsteps -= len;
+    }
+    return PSTAT_OK;
+  }
   const int64_t blocks = h->args.blocks_per_case * h->ncases;
   const char *env = getenv("PSTAT_SEGMENTS");
   if (const char *ms = getenv("PSTAT_MAX_SPINS")) h->args.max_spins = atoi(ms) > 0 ? atoi(ms) : h->args.max_spins;
@@ -356,6 +375,9 @@ int pstat_sync(pstat_handle *h) {
 
 int pstat_reinit(pstat_handle *h, int32_t force_init) {
   if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  if (h->base.energy_type == PSTAT_INTERACTING)
+    return fail(PSTAT_ERR_UNSUPPORTED, "re-initialisation (--num-inits > 1) is not implemented for "
+                "energy-type 'interacting'");
   int rc = set_device(h);
   if (rc) return rc;
   HIP_TRY(launch_reinit(h->cfg, h->args, h->S, h->d_cases, force_init, h->stream));
@@ -541,12 +563,13 @@ int pstat_launch_info_get(pstat_handle *h, pstat_launch_info *out) {
   std::memset(out, 0, sizeof *out);
   int lds = 0, bpc = 0;
   const char *name = "";
-  HIP_TRY(sweep_kernel_info(h->cfg, h->args, &lds, &bpc, &name));
+  if (h->base.energy_type == PSTAT_INTERACTING) HIP_TRY(interacting_kernel_info(h->cfg, &bpc, &name));
+  else HIP_TRY(sweep_kernel_info(h->cfg, h->args, &lds, &bpc, &name));
   std::snprintf(out->kernel, sizeof out->kernel, "%s", name);
   out->lds_bytes = lds;
   out->threads_per_block = 64;
   out->lanes_per_block = h->args.lanes;
-  out->blocks = h->args.blocks_per_case * h->ncases;
+  out->blocks = h->base.energy_type == PSTAT_INTERACTING ? h->S.C : h->args.blocks_per_case * h->ncases;
   out->blocks_per_cu = bpc;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));

@@ -1,0 +1,331 @@
+// pstat_interacting.hip -- gfx950 kernel for --energy-type interacting (inc/energy.jl:11-16,
+// U_interaction inc/eap_chain.jl:196-211): every trial move needs the O(n^2) dipole-dipole sum.
+//
+// Mapping: ONE CHAIN PER WAVEFRONT, lane i owns monomer i (n <= 64).  Per lane in registers: the
+// angles, n-hat, dipole and position of its monomer.  Everything that is one-per-chain (generator,
+// proposal, r, p, U, running sums) is wave-uniform: the generator lives in SGPRs and runs on the
+// scalar ALU beside the vector work.
+//   * trial positions: a move of monomer idx shifts x_idx by b/2 dn and every x_j, j > idx, by b dn
+//     (x_i = b (sum_{k<=i} n_k - n_i/2), inc/eap_chain.jl:49-51): three FMAs per lane, no scan;
+//   * the n(n-1)/2 pair terms: 32 lane rotations of (x, mu) with DPP `wave_ror:1` (no LDS traffic),
+//     lane i meets lane i-k at rotation k; rotation 32 is counted by the lower half only, so every
+//     pair is evaluated exactly once (2016 pairs at n = 64);
+//   * one butterfly reduction gives the new pair energy to all lanes.
+// Full recomputation per step is the reference's own cost model (it recomputes U from scratch,
+// inc/eap_chain.jl:254); an exact incremental form would still touch ~n^2/6 pairs twice.
+// No LDS, no barrier, no atomics; HBM only at launch start/end.
+#include "pstat_device.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/pstat.h"
+#include "pstat_math.h"
+
+namespace pstat {
+
+template <typename T>
+__device__ __forceinline__ T rotate1(T v);  // one lane step of the wave rotation used below
+template <>
+__device__ __forceinline__ float rotate1<float>(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C /* wave_ror:1 */, 0xF, 0xF, false));
+}
+template <>
+__device__ __forceinline__ int rotate1<int>(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xF, 0xF, false);
+}
+template <>
+__device__ __forceinline__ double rotate1<double>(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x13C, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x13C, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename R>
+__device__ __forceinline__ R wave_allsum(R v) {  // butterfly: every lane ends with the same bits
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <typename R>
+__device__ __forceinline__ R wave_incl_scan(R v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const R t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+template <typename R>
+__device__ __forceinline__ R lane_value(R v, int src);
+template <>
+__device__ __forceinline__ float lane_value<float>(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+template <>
+__device__ __forceinline__ double lane_value<double>(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// pair term with the f32 fast form (one v_rsq instead of sqrt + 4 divisions); the f64 form is
+// the literal expression of inc/eap_chain.jl:200-207
+__device__ __forceinline__ float pair_fast(float rx, float ry, float rz, float mix, float miy, float miz,
+                                           float mjx, float mjy, float mjz) {
+  const float r2 = rx * rx + ry * ry + rz * rz;
+  const float ir = __builtin_amdgcn_rsqf(r2);
+  const float ir2 = ir * ir;
+  const float mimj = mix * mjx + miy * mjy + miz * mjz;
+  const float mir = mix * rx + miy * ry + miz * rz;
+  const float mjr = mjx * rx + mjy * ry + mjz * rz;
+  return (mimj - 3.0f * mir * mjr * ir2) * (ir2 * ir) * 0.0795774715459476679f;  // 1/(4 pi)
+}
+__device__ __forceinline__ double pair_fast(double rx, double ry, double rz, double mix, double miy,
+                                            double miz, double mjx, double mjy, double mjz) {
+  return pair_term<double>(rx, ry, rz, mix, miy, miz, mjx, mjy, mjz);
+}
+
+template <typename R, int CT, int TRIG>
+__global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S,
+                                                         const CaseConst *__restrict__ cases,
+                                                         int do_flips, int use_lag) {
+  using AG = Ang<R, TRIG>;
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  const int64_t C = S.C;
+  const int n = (int)A.n;
+  const bool real = lane < n;
+  const CaseConst cc = cases[c / A.chains_per_case];
+  const R Fz = (R)cc.Fz, Fx = (R)cc.Fx, b = (R)cc.b, kT = (R)cc.kT;
+  const R a_or_mu = (CT == PSTAT_DIELECTRIC) ? (R)((cc.K1 - cc.K2) * cc.E0) : (R)cc.mu;
+  const R k2e = (R)(cc.K2 * cc.E0);
+  const R mhalfE0 = (R)(-0.5 * cc.E0);
+  const R nbeta_log2e = (R)(-1.4426950408889634 / cc.kT);
+  (void)kT; (void)nbeta_log2e;
+
+  // which lane feeds me after one rotation step (robust against the rotate direction convention)
+  const int delta = (rotate1<int>(lane) - lane) & 63;
+
+  // ---- fill: my monomer's angles; chain-level scalars are wave-uniform
+  const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
+  R th = real ? gth[(int64_t)lane * C + c] : (R)0;
+  R ph = real ? gph[(int64_t)lane * C + c] : (R)0;
+  Xoshiro128pp g;
+  g.s0 = __builtin_amdgcn_readfirstlane(S.rng[0 * C + c]);
+  g.s1 = __builtin_amdgcn_readfirstlane(S.rng[1 * C + c]);
+  g.s2 = __builtin_amdgcn_readfirstlane(S.rng[2 * C + c]);
+  g.s3 = __builtin_amdgcn_readfirstlane(S.rng[3 * C + c]);
+  double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
+  R phistep = (R)(phistep_d / AG::unit), thstep = (R)(thstep_d / AG::unit);
+  int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
+  int nacc_seg = 0, steps_seg = 0;
+  R lag = use_lag ? (R)S.lag[c] : (R)0;
+  double sums[NSUMS];
+#pragma unroll
+  for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
+
+  // ---- derive my monomer and the chain totals (inc/eap_chain.jl:109-134)
+  R st, ct, sp, cp, nx, ny, nz, mx, my, mz, xx, xy, xz;
+  R rx, ry, rz, px, py, pz, usum, upair, U;
+  auto derive = [&]() {
+    AG::sc(th, &st, &ct);
+    AG::sc(ph, &sp, &cp);
+    nx = real ? cp * st : (R)0; ny = real ? sp * st : (R)0; nz = real ? ct : (R)0;
+    dipole<R, CT>(a_or_mu, k2e, nx, ny, nz, mx, my, mz);
+    if (!real) { mx = 0; my = 0; mz = 0; }
+    xx = b * (wave_incl_scan<R>(nx, lane) - (R)0.5 * nx);
+    xy = b * (wave_incl_scan<R>(ny, lane) - (R)0.5 * ny);
+    xz = b * (wave_incl_scan<R>(nz, lane) - (R)0.5 * nz);
+    rx = b * wave_allsum<R>(nx); ry = b * wave_allsum<R>(ny); rz = b * wave_allsum<R>(nz);
+    px = wave_allsum<R>(mx); py = wave_allsum<R>(my); pz = wave_allsum<R>(mz);
+    usum = wave_allsum<R>(mhalfE0 * mz);
+  };
+  // sum over all pairs of the configuration (tx, tm) held one monomer per lane
+  auto pair_sum = [&](R tx, R ty, R tz, R tmx, R tmy, R tmz) -> R {
+    R qx = tx, qy = ty, qz = tz, qmx = tmx, qmy = tmy, qmz = tmz;
+    R e = 0;
+    int j = lane;
+#pragma unroll 4
+    for (int k = 1; k <= 32; ++k) {
+      qx = rotate1<R>(qx); qy = rotate1<R>(qy); qz = rotate1<R>(qz);
+      qmx = rotate1<R>(qmx); qmy = rotate1<R>(qmy); qmz = rotate1<R>(qmz);
+      j = (j + delta) & 63;
+      const bool valid = real && j < n && (k < 32 || lane < 32);
+      const R t = pair_fast(tx - qx, ty - qy, tz - qz, tmx, tmy, tmz, qmx, qmy, qmz);
+      e += valid ? t : (R)0;
+    }
+    return wave_allsum<R>(e);
+  };
+  derive();
+  upair = pair_sum(xx, xy, xz, mx, my, mz);
+  U = usum + upair - (rx * Fx + rz * Fz);
+
+  int64_t step = A.step0;
+  int64_t remaining = A.nsteps;
+  const int64_t spa = A.steps_per_adjust;
+  int64_t to_adj = A.adaptive ? spa - (step % spa) : 0;
+  constexpr int FLUSH = 128;
+
+  while (remaining > 0) {
+    int64_t chunk = remaining < FLUSH ? remaining : FLUSH;
+    if (A.adaptive && to_adj < chunk) chunk = to_adj;
+    R acc1[7], acc2[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) { acc1[q] = 0; acc2[q] = 0; }
+
+    for (int k = 0; k < (int)chunk; ++k) {
+      // ---- proposal (wave-uniform), mcmc_eap_chain.jl:277-280
+      const int idx = (int)__umulhi(g.next(), (uint32_t)n);
+      const R dphi = phistep * sym11<R>(g.next());
+      const R th0 = lane_value<R>(th, idx), ph0 = lane_value<R>(ph, idx);
+      R flip = 0;
+      if (do_flips && (g.next() >> 31)) flip = AG::theta_max - 2 * th0;
+      const R dth = flip + thstep * sym11<R>(g.next());
+      const R eps = u01<R>(g.next());
+      const R st0 = lane_value<R>(st, idx);
+      const R n0x = lane_value<R>(nx, idx), n0y = lane_value<R>(ny, idx), n0z = lane_value<R>(nz, idx);
+      const R m0x = lane_value<R>(mx, idx), m0y = lane_value<R>(my, idx), m0z = lane_value<R>(mz, idx);
+
+      // ---- move!, inc/eap_chain.jl:232-253
+      const R ph1 = AG::wrap(ph0 + dphi);
+      const R th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
+      R st1, ct1, sp1, cp1;
+      AG::sc(th1, &st1, &ct1);
+      AG::sc(ph1, &sp1, &cp1);
+      const R n1x = cp1 * st1, n1y = sp1 * st1, n1z = ct1;
+      R m1x, m1y, m1z;
+      dipole<R, CT>(a_or_mu, k2e, n1x, n1y, n1z, m1x, m1y, m1z);
+      const R dnx = n1x - n0x, dny = n1y - n0y, dnz = n1z - n0z;
+      const bool mine = lane == idx;
+      const R w = lane > idx ? b : (mine ? (R)0.5 * b : (R)0);   // shift of x_lane in units of dn
+      const R tx = fma_r(w, dnx, xx), ty = fma_r(w, dny, xy), tz = fma_r(w, dnz, xz);
+      const R tmx = mine ? m1x : mx, tmy = mine ? m1y : my, tmz = mine ? m1z : mz;
+
+      // ---- energy, inc/energy.jl:13-16: sum(us) + U_interaction - F.r
+      const R upair1 = pair_sum(tx, ty, tz, tmx, tmy, tmz);
+      const R du = mhalfE0 * (m1z - m0z);
+      const R drx = b * dnx, dry = b * dny, drz = b * dnz;
+      const R dpair = upair1 - upair;
+      const R dU = du + dpair - (Fx * drx + Fz * drz);
+
+      // ---- Metropolis, inc/acceptance.jl:18-39 (1/r^3 singularities give NaN => rejected)
+      bool ok;
+      if constexpr (sizeof(R) == 8) {
+        const R dlt = -dU / kT + log(st1 / st0) - lag;
+        ok = (dlt >= 0) || (eps < exp(dlt));
+      } else {
+        const R e = __builtin_amdgcn_exp2f((R)1.44269504f * (-lag) + dU * nbeta_log2e);
+        ok = eps * st0 < st1 * e;
+      }
+      ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;   // one decision per chain
+      if (ok) {
+        if (mine) {
+          th = th1; ph = ph1; st = st1;
+          nx = n1x; ny = n1y; nz = n1z; mx = m1x; my = m1y; mz = m1z;
+        }
+        xx = tx; xy = ty; xz = tz;
+        rx += drx; ry += dry; rz += drz;
+        px += m1x - m0x; py += m1y - m0y; pz += m1z - m0z;
+        usum += du; upair = upair1; U += dU;
+        lag = 0;
+        ++nacc_seg;
+      }
+      // ---- record! x 8, mcmc_eap_chain.jl:327-328
+      acc1[0] += rx; acc1[1] += ry; acc1[2] += rz; acc1[3] += px; acc1[4] += py; acc1[5] += pz; acc1[6] += U;
+      acc2[0] = fma_r(rx, rx, acc2[0]); acc2[1] = fma_r(ry, ry, acc2[1]); acc2[2] = fma_r(rz, rz, acc2[2]);
+      acc2[3] = fma_r(px, px, acc2[3]); acc2[4] = fma_r(py, py, acc2[4]); acc2[5] = fma_r(pz, pz, acc2[5]);
+      acc2[6] = fma_r(U, U, acc2[6]);
+    }
+
+    sums[S_R1] += (double)acc1[0]; sums[S_R2] += (double)acc1[1]; sums[S_R3] += (double)acc1[2];
+    sums[S_P1] += (double)acc1[3]; sums[S_P2] += (double)acc1[4]; sums[S_P3] += (double)acc1[5];
+    sums[S_U] += (double)acc1[6];
+    sums[S_R1SQ] += (double)acc2[0]; sums[S_R2SQ] += (double)acc2[1]; sums[S_R3SQ] += (double)acc2[2];
+    sums[S_P1SQ] += (double)acc2[3]; sums[S_P2SQ] += (double)acc2[4]; sums[S_P3SQ] += (double)acc2[5];
+    sums[S_USQ] += (double)acc2[6];
+    step += chunk;
+    remaining -= chunk;
+    steps_seg += (int)chunk;
+
+    if constexpr (sizeof(R) == 4) {
+      // f32 only: positions and totals are updated incrementally; re-derive them from the angles
+      // once per block of steps so rounding cannot drift (the pair energy is always a fresh sum)
+      const R keep_pair = upair;
+      derive();
+      upair = keep_pair;
+      U = usum + upair - (rx * Fx + rz * Fz);
+    }
+
+    if (A.adaptive) {  // mcmc_eap_chain.jl:301-322
+      to_adj -= chunk;
+      if (to_adj == 0) {
+        to_adj = spa;
+        const int nacc = nacc_off + nacc_seg, natt = natt_off + steps_seg;
+        const double ratio = (double)nacc / (double)natt;
+        if (ratio > A.adj_ub && phistep_d != K<double>::pi && thstep_d != K<double>::half_pi) {
+          nacc_off = -nacc_seg; natt_off = -steps_seg;
+          phistep_d = fmin(K<double>::pi, phistep_d * A.adj_scale);
+          thstep_d = fmin(K<double>::half_pi, thstep_d * A.adj_scale);
+        } else if (ratio < A.adj_lb) {
+          nacc_off = -nacc_seg; natt_off = -steps_seg;
+          phistep_d /= A.adj_scale;
+          thstep_d /= A.adj_scale;
+        }
+        phistep = (R)(phistep_d / AG::unit); thstep = (R)(thstep_d / AG::unit);
+      }
+    }
+  }
+
+  // ---- spill
+  if (real) {
+    R *wth = (R *)S.ang, *wph = (R *)S.ang + (int64_t)n * C;
+    wth[(int64_t)lane * C + c] = th;
+    wph[(int64_t)lane * C + c] = ph;
+  }
+  if (lane == 0) {
+    S.rng[0 * C + c] = g.s0; S.rng[1 * C + c] = g.s1; S.rng[2 * C + c] = g.s2; S.rng[3 * C + c] = g.s3;
+    S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
+    S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
+    S.nacc_total[c] += nacc_seg;
+    S.obs[OBS_R1 * C + c] = rx; S.obs[OBS_R2 * C + c] = ry; S.obs[OBS_R3 * C + c] = rz;
+    S.obs[OBS_P1 * C + c] = px; S.obs[OBS_P2 * C + c] = py; S.obs[OBS_P3 * C + c] = pz;
+    S.obs[OBS_U * C + c] = U; S.obs[OBS_USUM * C + c] = usum;
+    S.lag[c] = lag;
+    for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
+  }
+}
+
+using InterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int);
+
+static InterFn pick_interacting(const LaunchCfg &cfg) {
+  const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
+  if (cfg.precision == PSTAT_F64)
+    return diel ? interacting_kernel<double, PSTAT_DIELECTRIC, 0> : interacting_kernel<double, PSTAT_POLAR, 0>;
+  if (cfg.trig_mode == 0)
+    return diel ? interacting_kernel<float, PSTAT_DIELECTRIC, 0> : interacting_kernel<float, PSTAT_POLAR, 0>;
+  return diel ? interacting_kernel<float, PSTAT_DIELECTRIC, 1> : interacting_kernel<float, PSTAT_POLAR, 1>;
+}
+
+hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
+                              const CaseConst *cases, hipStream_t stream) {
+  InterFn fn = pick_interacting(cfg);
+  hipLaunchKernelGGL(fn, dim3((unsigned)s.C), dim3(64), 0, stream, a, s, cases, cfg.do_flips, cfg.lag);
+  return hipGetLastError();
+}
+
+hipError_t interacting_kernel_info(const LaunchCfg &cfg, int *blocks_per_cu, const char **name) {
+  InterFn fn = pick_interacting(cfg);
+  int nb = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fn, 64, 0);
+  if (e != hipSuccess) return e;
+  if (blocks_per_cu) *blocks_per_cu = nb;
+  if (name) *name = cfg.precision == PSTAT_F64 ? "interacting_kernel<double>" : "interacting_kernel<float>";
+  return hipSuccess;
+}
+
+}  // namespace pstat

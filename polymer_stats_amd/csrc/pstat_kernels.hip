@@ -25,114 +25,11 @@
 #include <math.h>
 
 #include "../../include/pstat.h"
+#include "pstat_math.h"
 
 namespace pstat {
 
-// ------------------------------------------------------------------------------------------ math
-
-template <typename R> struct Vec2;
-template <> struct Vec2<float> { using type = float2; };
-template <> struct Vec2<double> { using type = double2; };
-
-template <typename R> struct K;  // constants
-template <> struct K<float> {
-  static constexpr float pi = 3.14159274101257324f;  // (float)pi: > pi, so sin(pi) < 0 => clamp rejects
-  static constexpr float two_pi = 6.28318548202514648f;
-  static constexpr float half_pi = 1.57079637050628662f;
-};
-template <> struct K<double> {
-  static constexpr double pi = 3.14159265358979323846;
-  static constexpr double two_pi = 6.28318530717958647692;
-  static constexpr double half_pi = 1.57079632679489661923;
-};
-
-// TRIG modes for the f32 path: 0 = OCML sincosf (<= 2 ulp), 1 = hardware v_sin/v_cos through the
-// fast-math intrinsics, 2 = own Cody-Waite + minimax polynomials (|x| <= 2 pi assumed).
-template <int TRIG>
-__device__ __forceinline__ void sincos_r(float x, float *s, float *c) {
-  if constexpr (TRIG == 0) {
-    sincosf(x, s, c);
-  } else if constexpr (TRIG == 1) {
-    *s = __sinf(x);
-    *c = __cosf(x);
-  } else {
-    float q = rintf(x * 0.636619746685028076f);           // x * 2/pi
-    float r = __builtin_fmaf(q, -1.57079625129699707f, x);  // pi/2 split hi
-    r = __builtin_fmaf(q, -7.54978941586159635e-08f, r);    // pi/2 split lo
-    int k = (int)q;
-    float r2 = r * r;
-    float ps = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = __builtin_fmaf(ps, r2, -1.6666654611e-1f);
-    float sn = __builtin_fmaf(ps * r2, r, r);
-    float pc = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = __builtin_fmaf(pc, r2, 4.166664568298827e-2f);
-    float cs = __builtin_fmaf(pc * r2, r2, __builtin_fmaf(r2, -0.5f, 1.0f));
-    float ss = (k & 1) ? cs : sn;
-    float cc = (k & 1) ? sn : cs;
-    *s = (k & 2) ? -ss : ss;
-    *c = ((k + 1) & 2) ? -cc : cc;
-  }
-}
-template <int TRIG>
-__device__ __forceinline__ void sincos_r(double x, double *s, double *c) {
-  sincos(x, s, c);
-}
-
-__device__ __forceinline__ float exp_r(float x) { return __expf(x); }
-__device__ __forceinline__ double exp_r(double x) { return exp(x); }
-__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_r(double a, double b, double c) { return a * b + c; }
-
-// u(w) = (w >> 9) * 2^-23 in [0,1).  v_cvt_f32_u32 is a quarter-rate instruction on gfx950, so the
-// f32 forms splice the 23 bits into the mantissa of a float in [1,2) (or [2,4) for 2u-1) instead:
-// two full-rate integer ops and one add, and the result is exactly the same number.
-template <typename R>
-__device__ __forceinline__ R u01(uint32_t w) {
-  if constexpr (sizeof(R) == 4) return __uint_as_float(0x3F800000u | (w >> 9)) - 1.0f;
-  else return (R)(w >> 9) * (R)(1.0 / 8388608.0);
-}
-template <typename R>
-__device__ __forceinline__ R sym11(uint32_t w) {  // 2u - 1 in [-1,1)
-  if constexpr (sizeof(R) == 4) return __uint_as_float(0x40000000u | (w >> 9)) - 3.0f;
-  else return (R)2 * ((R)(w >> 9) * (R)(1.0 / 8388608.0)) - (R)1;
-}
-
-// dipole of one monomer: inc/dipole_response.jl:7-11 (dielectric), :27-29 with M = mu*I (polar)
-template <typename R, int CT>
-__device__ __forceinline__ void dipole(R a_or_mu, R k2e, R nx, R ny, R nz, R &mx, R &my, R &mz) {
-  if constexpr (CT == PSTAT_DIELECTRIC) {
-    R a = a_or_mu * nz;  // (K1-K2) E0 cos(theta)
-    mx = a * nx; my = a * ny; mz = a * nz + k2e;
-  } else {
-    mx = a_or_mu * nx; my = a_or_mu * ny; mz = a_or_mu * nz;
-  }
-}
-
-// one dipole-dipole term (inc/eap_chain.jl:200-207) for a bond vector r = x_i - x_j
-template <typename R>
-__device__ __forceinline__ R pair_term(R rx, R ry, R rz, R mix, R miy, R miz, R mjx, R mjy, R mjz) {
-  R r2 = rx * rx + ry * ry + rz * rz;
-  R rmag = sqrt(r2);
-  R hx = rx / rmag, hy = ry / rmag, hz = rz / rmag;
-  R r3 = r2 * rmag;
-  R mimj = mix * mjx + miy * mjy + miz * mjz;
-  R mir = mix * hx + miy * hy + miz * hz;
-  R mjr = mjx * hx + mjy * hy + mjz * hz;
-  return (mimj - 3 * mir * mjr) / ((R)(4.0 * 3.14159265358979323846) * r3);
-}
-
 // ------------------------------------------------------------------------------------------ init
-
-// stored angle unit: radians for f64, turns for f32 (see Ang<> below)
-template <typename R> __host__ __device__ constexpr double ang_unit() {
-  return sizeof(R) == 4 ? 6.28318530717958647692 : 1.0;
-}
-template <typename R> __device__ __forceinline__ R store_phi(double u) {   // phi ~ U(0, 2pi)
-  return sizeof(R) == 4 ? (R)u : (R)(6.28318530717958647692 * u);
-}
-template <typename R> __device__ __forceinline__ R store_theta(double u) { // theta ~ U(0, pi)
-  return sizeof(R) == 4 ? (R)(0.5 * u) : (R)(3.14159265358979323846 * u);
-}
 
 // EAPChain(pargs), inc/eap_chain.jl:60-135: all phi draws, then all theta draws; then r, p, U.
 // One thread per chain; angles are rounded to the storage type R before anything is derived.
@@ -184,34 +81,6 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
 }
 
 // ------------------------------------------------------------------------------------------ sweep
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-// Angle representation per arithmetic type.
-//   f64: radians, exactly the reference's variables (bit-reproduces the CPU oracle).
-//   f32: TURNS (theta/2pi in [0, 1/2], phi/2pi in [0, 1)).  gfx950's v_sin_f32/v_cos_f32 take turns
-//        and are accurate to 1.3e-7 absolute there (tools/ubench), phi wraps with one v_fract, and
-//        no range reduction or 1/2pi pre-scale is ever needed.
-template <typename R, int TRIG> struct Ang;
-template <int TRIG> struct Ang<double, TRIG> {
-  static constexpr double theta_max = 3.14159265358979323846;
-  static constexpr double unit = 1.0;  // radians per stored unit
-  static __device__ __forceinline__ void sc(double x, double *s, double *c) { sincos(x, s, c); }
-  static __device__ __forceinline__ double wrap(double x) { return x; }  // phi random-walks, eap_chain.jl:232
-};
-template <int TRIG> struct Ang<float, TRIG> {
-  static constexpr float theta_max = 0.5f;
-  static constexpr double unit = 6.28318530717958647692;
-  static __device__ __forceinline__ void sc(float x, float *s, float *c) {
-    if constexpr (TRIG == 0) {
-      sincosf(x * 6.28318548202514648f, s, c);  // OCML reference path (A/B only)
-    } else {
-      *s = __builtin_amdgcn_sinf(x);
-      *c = __builtin_amdgcn_cosf(x);
-    }
-  }
-  static __device__ __forceinline__ float wrap(float x) { return __builtin_amdgcn_fractf(x); }
-};
 
 struct Draw {  // raw words of one step's proposal, mcmc_eap_chain.jl:277-280,287
   uint32_t idx, wphi, wth, weps, wflip;

@@ -59,6 +59,31 @@ def test_f64_bit_parity_ising(ps, oracle):
                 steps_per_adjust=400)
 
 
+def test_f64_bit_parity_interacting(ps, oracle):
+    # BASELINE configs[3] family: dipole-dipole interacting dielectric chain, one chain per wavefront
+    _bit_parity(ps, oracle, 1500, 6, n=64, E0=1.0, K1=1.0, K2=0.0, Fz=0.5, energy_type=1, seed=13,
+                steps_per_adjust=300)
+
+
+def test_f64_bit_parity_interacting_short_polar_flips(ps, oracle):
+    _bit_parity(ps, oracle, 1500, 5, n=23, E0=1.2, mu=0.8, Fz=0.3, Fx=0.2, chain_type=1, energy_type=1,
+                do_flips=1, seed=14, steps_per_adjust=250)
+
+
+def test_f32_interacting_statistical_parity(ps, oracle):
+    """f32 interacting kernel vs CPU oracle (faithful = full O(n^2) recompute) under the same
+    protocol: pooled means within 4.5 sigma."""
+    nsteps, nch = 4000, 1024
+    op, pp = both(nsteps, num_chains=nch, precision=ps.F32, n=32, E0=1.0, K1=1.0, Fz=0.5, energy_type=1, seed=15)
+    with ps.Ensemble(pp) as e:
+        e.advance(nsteps)
+        g_avg, g_se = e.rolling()
+    osums, onorm, _ = oracle.run_many(op, 5_000_000, 128, nthreads=8, mode="faithful")
+    o_avg, o_se = pooled(osums, onorm)
+    z = (g_avg - o_avg) / np.sqrt(g_se ** 2 + o_se ** 2 + 1e-300)
+    assert np.all(np.abs(z) < 4.5), dict(zip(ps.OBS_NAMES, np.round(z, 2)))
+
+
 def test_f64_bit_parity_no_adaptation_single_monomer(ps, oracle):
     _bit_parity(ps, oracle, 3000, 3, n=1, E0=2.0, K1=1.0, Fz=0.5, adj_scale=1.0, seed=2)
 
@@ -207,5 +232,5 @@ def test_errors_are_loud(ps):
     with pytest.raises(ps.PstatError):
         ps.Ensemble(ps.default_params(kT=0.0))
     with pytest.raises(ps.PstatError) as ei:
-        ps.Ensemble(ps.default_params(energy_type=ps.INTERACTING))
+        ps.Ensemble(ps.default_params(energy_type=ps.INTERACTING, n=100))   # > one wavefront
     assert ei.value.code == -4
