@@ -87,8 +87,8 @@ int validate(const pstat_params *c, int ncases) {
   if (b.energy_type == PSTAT_INTERACTING && b.n > 64)
     return fail(PSTAT_ERR_UNSUPPORTED, "energy-type 'interacting' runs one chain per 64-lane wavefront: "
                 "num-monomers must be <= 64 (got %lld)", (long long)b.n);
-  if (b.umbrella)
-    return fail(PSTAT_ERR_UNSUPPORTED, "umbrella sampling has no device kernel yet");
+  if (b.umbrella && b.energy_type == PSTAT_INTERACTING)
+    return fail(PSTAT_ERR_UNSUPPORTED, "umbrella sampling is not implemented for energy-type 'interacting'");
   if (b.precision != PSTAT_F32 && b.precision != PSTAT_F64)
     return fail(PSTAT_ERR_INVALID_ARG, "precision must be PSTAT_F32 or PSTAT_F64");
   if (!(b.phi_step > 0) || !(b.theta_step > 0))
@@ -256,6 +256,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_TRY(alloc(h, (void **)&S.sums, NSUMS * Cz * sizeof(double)));
   CREATE_TRY(alloc(h, (void **)&S.wnorm, Cz * sizeof(double)));
   CREATE_TRY(alloc(h, (void **)&S.lag, Cz * sizeof(double)));
+  CREATE_TRY(alloc(h, (void **)&S.uref, Cz * sizeof(double)));
   const size_t nstate = h->bufs.size();
   CREATE_TRY(alloc(h, &S.ang_tmp, 2 * n * Cz * h->elem));
   CREATE_TRY(alloc(h, (void **)&h->d_cases, sizeof(CaseConst) * (size_t)ncases));
@@ -456,7 +457,7 @@ int pstat_microstate(pstat_handle *h, int64_t chain, double out[7]) {
 }
 
 int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sums[PSTAT_NOBS],
-                      int64_t counters[4], double steps[2], uint32_t rng[4]) {
+                      int64_t counters[4], double steps[3], uint32_t rng[4]) {
   if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
   if (chain < 0 || chain >= h->S.C) return fail(PSTAT_ERR_INVALID_ARG, "chain out of range");
   int rc = set_device(h);
@@ -492,22 +493,25 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sum
     HIP_TRY(hipMemcpy(&tot, h->S.nacc_total + chain, sizeof tot, hipMemcpyDeviceToHost));
     counters[0] = tot; counters[1] = h->steps_recorded; counters[2] = w[0]; counters[3] = w[1];
   }
-  if (steps)
+  if (steps) {
     HIP_TRY(hipMemcpy2D(steps, sizeof(double), h->S.stepsz + chain, C * sizeof(double), sizeof(double), 2,
                         hipMemcpyDeviceToHost));
+    if (h->cfg.umbrella) HIP_TRY(hipMemcpy(&steps[2], h->S.wnorm + chain, sizeof(double), hipMemcpyDeviceToHost));
+    else steps[2] = (double)h->steps_recorded;
+  }
   if (rng)
     HIP_TRY(hipMemcpy2D(rng, sizeof(uint32_t), h->S.rng + chain, C * sizeof(uint32_t), sizeof(uint32_t), 4,
                         hipMemcpyDeviceToHost));
   return PSTAT_OK;
 }
 
-// checkpoint image: header, then the nine state buffers in allocation order
+// checkpoint image: header, then the ten state buffers in allocation order
 struct CkptHeader {
   uint64_t magic;
   int64_t n, C, ncases, steps_recorded, step_in_init;
   int32_t precision, chain_type, energy_type, reserved;
 };
-static const int kStateBuffers = 9;
+static const int kStateBuffers = 10;
 
 int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes) {
   if (!h || !bytes) return fail(PSTAT_ERR_INVALID_ARG, "null argument");

@@ -29,6 +29,9 @@ struct DevState {
   double *sums;         // f64[NSUMS][C]  averager .value fields (inc/average.jl:9)
   double *wnorm;        // f64[C]         averager .normalizer under umbrella sampling
   double *lag;          // f64[C]         acceptor's cached log-pi minus the chain's own (re-init)
+  double *uref;         // f64[C]         sum(u) of the chain's first configuration: the umbrella weights
+                        //                are taken relative to it (a per-chain constant factor cancels
+                        //                in value/normalizer, inc/average.jl:38,63-67)
   int64_t C;
 };
 

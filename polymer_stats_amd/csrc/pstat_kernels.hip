@@ -77,6 +77,7 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
   for (int q = 0; q < NSUMS; ++q) S.sums[q * S.C + c] = 0.0;
   S.wnorm[c] = 0.0;
   S.lag[c] = 0.0;
+  S.uref[c] = usum;
   (void)omega;
 }
 
@@ -103,6 +104,7 @@ __device__ __forceinline__ Draw draw_step(Xoshiro128pp &g, uint32_t n, bool flip
 struct SweepRare {  // wave-uniform switches of the rarely used options (RARE instantiations only)
   int flips;        // --do-flips
   int lag;          // a re-init happened: the acceptor's cached log-pi may be offset (see reinit_kernel)
+  int umb;          // --umbrella-sampling: AntiDipoleWeightFunction + UmbrellaAverager
 };
 
 // One time-segment of one chain block: fill LDS/registers from HBM, run `nsteps` steps, spill.
@@ -150,6 +152,12 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   O[6] = (R)S.obs[OBS_U * C + c]; O[7] = 0;
   R usum = (R)S.obs[OBS_USUM * C + c];
   R lag = RARE ? (R)S.lag[c] : (R)0;
+  // umbrella sampling (inc/average.jl:104-124): w = sum(u) * wscale - log_gauge enters log pi, and
+  // every record is weighted by 1/e^w.  Only w - w(first configuration) is ever needed here.
+  const bool umb = RARE && rare.umb;
+  const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
+  const R uref = umb ? (R)S.uref[c] : (R)0;
+  double wnorm = umb ? S.wnorm[c] : 0.0;
   double sums[NSUMS];
 #pragma unroll
   for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
@@ -171,6 +179,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     R acc1[8], acc2[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { acc1[q] = 0; acc2[q] = 0; }
+    R accw = 0;
 
     for (int k = 0; k < (int)chunk; ++k) {
       const bool more = remaining - k > 1;  // wave-uniform
@@ -237,13 +246,15 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
 
       // ---- Metropolis, inc/acceptance.jl:18-39.  pi ~ exp(-U/kT) * prod sin(theta)
       bool ok;
+      R dw = 0;
+      if constexpr (RARE) dw = du * wscale;   // change of the umbrella weight function (0 if off)
       if constexpr (sizeof(R) == 8) {
-        const R delta = -dU / kT + log(st1 / st0) - lag;
+        const R delta = -dU / kT + log(st1 / st0) + dw - lag;
         ok = (delta >= 0) || (eps < exp(delta));
       } else {
-        // same test with the logarithm folded away: eps * sin(th0) < sin(th1) * exp(-dU/kT - lag)
+        // same test with the logarithm folded away: eps * sin(th0) < sin(th1) * exp(-dU/kT + dw - lag)
         R e;
-        if constexpr (RARE) e = __builtin_amdgcn_exp2f((R)1.44269504f * (-lag) + dU * nbeta_log2e);
+        if constexpr (RARE) e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lag) + dU * nbeta_log2e);
         else                e = __builtin_amdgcn_exp2f(dU * nbeta_log2e);
         ok = eps * st0 < st1 * e;
       }
@@ -264,8 +275,15 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       }
 
       // ---- record! x 8, mcmc_eap_chain.jl:327-328 (every step, accepted or not)
+      if (umb) {  // UmbrellaAverager: value += v / e^w, normalizer += 1 / e^w
+        const R wgt = exp_r(-(usum - uref) * wscale);
+        accw += wgt;
 #pragma unroll
-      for (int q = 0; q < 7; ++q) { acc1[q] += O[q]; acc2[q] = fma_r(O[q], O[q], acc2[q]); }
+        for (int q = 0; q < 7; ++q) { acc1[q] = fma_r(wgt, O[q], acc1[q]); acc2[q] = fma_r(wgt * O[q], O[q], acc2[q]); }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { acc1[q] += O[q]; acc2[q] = fma_r(O[q], O[q], acc2[q]); }
+      }
       d = dn;
       a0 = an;
     }
@@ -276,6 +294,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     sums[S_R1SQ] += (double)acc2[0]; sums[S_R2SQ] += (double)acc2[1]; sums[S_R3SQ] += (double)acc2[2];
     sums[S_P1SQ] += (double)acc2[3]; sums[S_P2SQ] += (double)acc2[4]; sums[S_P3SQ] += (double)acc2[5];
     sums[S_USQ] += (double)acc2[6];
+    wnorm += (double)accw;
     step += chunk;
     remaining -= chunk;
     steps_seg += (int)chunk;
@@ -317,7 +336,10 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   S.obs[OBS_R1 * C + c] = O[0]; S.obs[OBS_R2 * C + c] = O[1]; S.obs[OBS_R3 * C + c] = O[2];
   S.obs[OBS_P1 * C + c] = O[3]; S.obs[OBS_P2 * C + c] = O[4]; S.obs[OBS_P3 * C + c] = O[5];
   S.obs[OBS_U * C + c] = O[6]; S.obs[OBS_USUM * C + c] = usum;
-  if constexpr (RARE) S.lag[c] = lag;
+  if constexpr (RARE) {
+    S.lag[c] = lag;
+    if (umb) S.wnorm[c] = wnorm;
+  }
 #pragma unroll
   for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
 }
@@ -583,7 +605,7 @@ hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(queue, 0, sizeof(int) * sweep_queue_ints(a), stream);
   if (e != hipSuccess) return e;
-  SweepRare rare{cfg.do_flips, cfg.lag};
+  SweepRare rare{cfg.do_flips, cfg.lag, cfg.umbrella};
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a, s, cases, rare, queue);
   return hipGetLastError();
 }

@@ -85,7 +85,7 @@ class Ensemble:
         ang = np.zeros(2 * self.n)
         sums = np.zeros(NOBS)
         cnt = np.zeros(4, dtype=np.int64)
-        steps = np.zeros(2)
+        steps = np.zeros(3)
         rng = np.zeros(4, dtype=np.uint32)
         dp = C.POINTER(C.c_double)
         check(self._L.pstat_chain_state(self._h, chain, ang.ctypes.data_as(dp), sums.ctypes.data_as(dp),
@@ -93,7 +93,7 @@ class Ensemble:
                                         rng.ctypes.data_as(C.POINTER(C.c_uint32))))
         return dict(theta=ang[:self.n], phi=ang[self.n:], sums=sums, nacc_total=int(cnt[0]),
                     steps_recorded=int(cnt[1]), nacc_window=int(cnt[2]), natt_window=int(cnt[3]),
-                    phi_step=steps[0], theta_step=steps[1], rng=rng)
+                    phi_step=steps[0], theta_step=steps[1], normalizer=steps[2], rng=rng)
 
     def checkpoint(self) -> bytes:
         size = C.c_size_t(0)

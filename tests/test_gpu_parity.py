@@ -84,6 +84,37 @@ def test_f32_interacting_statistical_parity(ps, oracle):
     assert np.all(np.abs(z) < 4.5), dict(zip(ps.OBS_NAMES, np.round(z, 2)))
 
 
+def test_f64_umbrella_parity(ps, oracle):
+    """--umbrella-sampling: the weight function enters the acceptance and every record is weighted
+    by 1/e^w (inc/average.jl:52-124).  Trajectory bit-exact; per-chain averages (value/normalizer,
+    in which the gauge constant cancels) to 1e-9."""
+    for kw in (dict(n=14, E0=1.0, K1=1.0, K2=0.2, Fz=0.5), dict(n=9, E0=1.0, mu=0.5, Fz=0.2, chain_type=1, energy_type=2)):
+        nsteps = 4000
+        op, pp = both(nsteps, num_chains=64, precision=ps.F64, umbrella=1, seed=19, steps_per_adjust=500, **kw)
+        with ps.Ensemble(pp) as e:
+            e.advance(nsteps)
+            for c in (0, 31, 63):
+                o = oracle.run(op, chain_id=c, mode="fast", trace=True)
+                g = e.chain_state(c)
+                assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi)
+                assert g["nacc_total"] == o.nacc_total
+                np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-9, atol=1e-9)
+
+
+def test_f32_umbrella_matches_plain_sampling(ps):
+    """The reference's own cross-check (run/noninteracting-compare-with-clustering_2021-09-24.jl):
+    umbrella-weighted and plain sampling estimate the same averages."""
+    out = {}
+    for umb in (0, 1):
+        pp = ps.default_params(num_chains=2048, precision=ps.F32, n=10, E0=0.8, K1=1.0, Fz=0.3, seed=8 + umb,
+                               umbrella=umb)
+        with ps.Ensemble(pp) as e:
+            e.advance(40000)
+            out[umb] = e.rolling()
+    z = (out[0][0] - out[1][0]) / np.sqrt(out[0][1] ** 2 + out[1][1] ** 2 + 1e-300)
+    assert np.all(np.abs(z) < 4.5), z
+
+
 def test_f64_bit_parity_no_adaptation_single_monomer(ps, oracle):
     _bit_parity(ps, oracle, 3000, 3, n=1, E0=2.0, K1=1.0, Fz=0.5, adj_scale=1.0, seed=2)
 
