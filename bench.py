@@ -94,7 +94,14 @@ def main():
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank")
     args = ap.parse_args()
+
+    # Libraries (RCCL's version banner, HIP warnings) may write to stdout; the contract is ONE JSON
+    # line there.  Park the real stdout and send everything else to stderr until the line is printed.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -108,9 +115,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libpstat has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     prec = ps.F64 if args.precision == "f64" else ps.F32
     stream = torch.cuda.Stream()
@@ -135,7 +144,7 @@ def main():
             if ev:
                 ev[1].record(stream)
             e.reduce_into(red.data_ptr())
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(red)
 
         for i in range(args.warmup):
@@ -144,7 +153,7 @@ def main():
             torch.cuda.synchronize()
             log(f"rank {rank}: warmup step {i} took {time.perf_counter() - tw:.3f} s")
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for _ in range(args.steps)]
@@ -153,14 +162,14 @@ def main():
         for i in range(args.steps):
             one_step(ens[args.warmup + i], events[i])
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         log(f"rank {rank}: {args.steps} timed steps in {elapsed:.3f} s")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in events]
@@ -213,10 +222,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.n, args.mc_steps)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     for e in ens:
         e.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -200,7 +200,11 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
             h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, trig_mode_from_env()};
 
   const bool inter = h->base.energy_type == PSTAT_INTERACTING;
-  const int lanes = inter ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
+  int lanes = inter ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
+  if (const char *le = getenv("PSTAT_LANES")) {  // experiment knob: fewer active lanes per wave
+    const int v = atoi(le);
+    if (!inter && v >= 1 && v <= lanes) lanes = v;
+  }
   if (lanes == 0) {
     delete h;
     return fail(PSTAT_ERR_UNSUPPORTED, "num-monomers = %lld does not fit the 160 KiB LDS of a CU",
