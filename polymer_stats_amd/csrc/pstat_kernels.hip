@@ -170,19 +170,25 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // software pipeline: the draws and the LDS row of the NEXT step are fetched while the current
   // step computes; if both steps hit the same monomer and the current one is accepted, the
   // prefetched row is replaced by the freshly accepted angles.
+  using P = typename V2<R>::type;   // {old, new}
   Draw d = draw_step<RARE>(g, (uint32_t)n, flips);
   R2 a0 = ang[d.idx * lanes + lane];
+  int left = (int)remaining;        // steps still to run in this segment (<= 2^30)
+  // running observables: (rx, ry) and (px, py) as pairs, the z components and U as scalars
+  P Orxy = {O[0], O[1]}, Opxy = {O[3], O[4]};
+  R Orz = O[2], Opz = O[5], OU = O[6];
+  const P bb = {b, b};
+  (void)bb;
 
-  while (remaining > 0) {
-    int64_t chunk = remaining < FLUSH ? remaining : FLUSH;
-    if (A.adaptive && to_adj < chunk) chunk = to_adj;
-    R acc1[8], acc2[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { acc1[q] = 0; acc2[q] = 0; }
+  while (left > 0) {
+    int chunk = left < FLUSH ? left : FLUSH;
+    if (A.adaptive && to_adj < chunk) chunk = (int)to_adj;
+    P a1rxy = {0, 0}, a1pxy = {0, 0}, a2rxy = {0, 0}, a2pxy = {0, 0};
+    R a1rz = 0, a1pz = 0, a1U = 0, a2rz = 0, a2pz = 0, a2U = 0;
     R accw = 0;
 
-    for (int k = 0; k < (int)chunk; ++k) {
-      const bool more = remaining - k > 1;  // wave-uniform
+    for (int k = 0; k < chunk; ++k) {
+      const bool more = left - k > 1;  // wave-uniform (scalar compare)
       Draw dn = d;
       R2 an = a0;
       if (more) {
@@ -191,33 +197,51 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       }
       // ---- proposal, mcmc_eap_chain.jl:277-280
       const R th0 = a0.x, ph0 = a0.y;
-      const R dphi = phistep * sym11<R>(d.wphi);
       R flip = 0;
       if constexpr (RARE) {
         if (flips && (d.wflip >> 31)) flip = AG::theta_max - 2 * th0;
       }
-      const R dth = flip + thstep * sym11<R>(d.wth);
       const R eps = u01<R>(d.weps);
 
       // ---- move!, inc/eap_chain.jl:232-245 (trial values; committed by selects below)
-      const R ph1 = AG::wrap(ph0 + dphi);
-      const R th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
+      R ph1, th1;
+      if constexpr (sizeof(R) == 8) {
+        const R dphi = phistep * sym11<R>(d.wphi);
+        const R dth = flip + thstep * sym11<R>(d.wth);
+        ph1 = AG::wrap(ph0 + dphi);
+        th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
+      } else {
+        ph1 = AG::wrap(fma_r(phistep, sym11<R>(d.wphi), ph0));
+        th1 = fmin(AG::theta_max, fmax((R)0, fma_r(thstep, sym11<R>(d.wth), th0 + flip)));
+      }
       R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
       AG::sc(th0, &st0, &ct0);
       AG::sc(th1, &st1, &ct1);
       AG::sc(ph0, &sp0, &cp0);
       AG::sc(ph1, &sp1, &cp1);
-      const R n0x = cp0 * st0, n0y = sp0 * st0, n0z = ct0;
-      const R n1x = cp1 * st1, n1y = sp1 * st1, n1z = ct1;
-      R m0x, m0y, m0z, m1x, m1y, m1z;
-      dipole<R, CT>(a_or_mu, k2e, n0x, n0y, n0z, m0x, m0y, m0z);
-      dipole<R, CT>(a_or_mu, k2e, n1x, n1y, n1z, m1x, m1y, m1z);
+      // (x, y) components travel as one 2-vector: {n_x, n_y} = sin(theta) * {cos(phi), sin(phi)}
+      // (inc/eap_chain.jl:40), so the old->new differences come out packed with no shuffles
+      const P cs0 = {cp0, sp0}, cs1 = {cp1, sp1};
+      const P s0s = {st0, st0}, s1s = {st1, st1};
+      const P Nxy0 = cs0 * s0s, Nxy1 = cs1 * s1s;
+      P Mxy0, Mxy1;
+      R mz0, mz1;                                         // dipole, inc/dipole_response.jl:7-29
+      if constexpr (CT == PSTAT_DIELECTRIC) {
+        const R q0 = a_or_mu * ct0, q1 = a_or_mu * ct1;  // (K1-K2) E0 cos(theta)
+        const P q0s = {q0, q0}, q1s = {q1, q1};
+        Mxy0 = q0s * Nxy0; Mxy1 = q1s * Nxy1;
+        mz0 = q0 * ct0 + k2e; mz1 = q1 * ct1 + k2e;
+      } else {
+        const P mus = {a_or_mu, a_or_mu};
+        Mxy0 = mus * Nxy0; Mxy1 = mus * Nxy1;
+        mz0 = a_or_mu * ct0; mz1 = a_or_mu * ct1;
+      }
+      const P dNxy = Nxy1 - Nxy0, dMxy = Mxy1 - Mxy0;
+      const R dnz = ct1 - ct0, dmz = mz1 - mz0;
 
       // ---- energy difference, inc/energy.jl:7-9,20-23; inc/eap_chain.jl:53
-      const R du = mhalfE0 * (m1z - m0z);
-      R dO[8];
-      dO[0] = b * (n1x - n0x); dO[1] = b * (n1y - n0y); dO[2] = b * (n1z - n0z);
-      dO[3] = m1x - m0x; dO[4] = m1y - m0y; dO[5] = m1z - m0z;
+      const R du = mhalfE0 * dmz;
+      const R drz = b * dnz;
       R dpair = 0;
       if constexpr (EN == PSTAT_ISING) {
         R e0 = 0, e1 = 0;
@@ -231,18 +255,17 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
             AG::sc(aj.y, &spj, &cpj);
             const R njx = cpj * sj, njy = spj * sj, njz = cj;
             dipole<R, CT>(a_or_mu, k2e, njx, njy, njz, mjx, mjy, mjz);
-            e0 += pair_term<R>(hb * (n0x + njx), hb * (n0y + njy), hb * (n0z + njz),
-                               m0x, m0y, m0z, mjx, mjy, mjz);
-            e1 += pair_term<R>(hb * (n1x + njx), hb * (n1y + njy), hb * (n1z + njz),
-                               m1x, m1y, m1z, mjx, mjy, mjz);
+            e0 += pair_term<R>(hb * (Nxy0.x + njx), hb * (Nxy0.y + njy), hb * (ct0 + njz),
+                               Mxy0.x, Mxy0.y, mz0, mjx, mjy, mjz);
+            e1 += pair_term<R>(hb * (Nxy1.x + njx), hb * (Nxy1.y + njy), hb * (ct1 + njz),
+                               Mxy1.x, Mxy1.y, mz1, mjx, mjy, mjz);
           }
         }
         dpair = e1 - e0;
       }
       R dU;
-      if constexpr (FX) dU = du + dpair - (Fx * dO[0] + Fz * dO[2]);
-      else              dU = du + dpair - (Fz * dO[2]);
-      dO[6] = dU; dO[7] = 0;
+      if constexpr (FX) dU = du + dpair - (Fx * (b * dNxy.x) + Fz * drz);
+      else              dU = du + dpair - (Fz * drz);
 
       // ---- Metropolis, inc/acceptance.jl:18-39.  pi ~ exp(-U/kT) * prod sin(theta)
       bool ok;
@@ -263,10 +286,24 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       R2 a1; a1.x = ok ? th1 : th0; a1.y = ok ? ph1 : ph0;
       ang[d.idx * lanes + lane] = a1;
       const R m = ok ? (R)1 : (R)0;
-#pragma unroll
-      for (int q = 0; q < 7; ++q) O[q] = fma_r(m, dO[q], O[q]);
-      usum = fma_r(m, du, usum);
-      if constexpr (RARE) lag = ok ? (R)0 : lag;
+      const P mm = {m, m};
+      if constexpr (sizeof(R) == 8) {  // the oracle's update order: r += b*dn, p += dm, U += dU
+        Orxy = pfma(mm, bb * dNxy, Orxy);
+        Orz = m * drz + Orz;
+      } else {
+        const R mb = m * b;
+        const P mbs = {mb, mb};
+        Orxy = pfma(mbs, dNxy, Orxy);
+        Orz = fma_r(mb, dnz, Orz);
+      }
+      Opxy = pfma(mm, dMxy, Opxy);
+      Opz = fma_r(m, dmz, Opz);
+      if constexpr (EN == PSTAT_ISING) OU = ok ? OU + dU : OU;  // dU may be inf/NaN (1/r^3): 0*NaN would poison U
+      else                             OU = fma_r(m, dU, OU);
+      if constexpr (RARE) {
+        usum = fma_r(m, du, usum);
+        lag = ok ? (R)0 : lag;
+      }
       nacc_seg += ok ? 1 : 0;
       if (more) {  // forward the accepted angles into the prefetched row if it is the same monomer
         const bool same = dn.idx == d.idx;
@@ -277,17 +314,24 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       // ---- record! x 8, mcmc_eap_chain.jl:327-328 (every step, accepted or not)
       if (umb) {  // UmbrellaAverager: value += v / e^w, normalizer += 1 / e^w
         const R wgt = exp_r(-(usum - uref) * wscale);
+        const P ww = {wgt, wgt};
         accw += wgt;
-#pragma unroll
-        for (int q = 0; q < 7; ++q) { acc1[q] = fma_r(wgt, O[q], acc1[q]); acc2[q] = fma_r(wgt * O[q], O[q], acc2[q]); }
+        a1rxy = pfma(ww, Orxy, a1rxy); a1pxy = pfma(ww, Opxy, a1pxy);
+        a2rxy = pfma(ww * Orxy, Orxy, a2rxy); a2pxy = pfma(ww * Opxy, Opxy, a2pxy);
+        a1rz = fma_r(wgt, Orz, a1rz); a1pz = fma_r(wgt, Opz, a1pz); a1U = fma_r(wgt, OU, a1U);
+        a2rz = fma_r(wgt * Orz, Orz, a2rz); a2pz = fma_r(wgt * Opz, Opz, a2pz); a2U = fma_r(wgt * OU, OU, a2U);
       } else {
-#pragma unroll
-        for (int q = 0; q < 7; ++q) { acc1[q] += O[q]; acc2[q] = fma_r(O[q], O[q], acc2[q]); }
+        a1rxy += Orxy; a1pxy += Opxy;
+        a2rxy = pfma(Orxy, Orxy, a2rxy); a2pxy = pfma(Opxy, Opxy, a2pxy);
+        a1rz += Orz; a1pz += Opz; a1U += OU;
+        a2rz = fma_r(Orz, Orz, a2rz); a2pz = fma_r(Opz, Opz, a2pz); a2U = fma_r(OU, OU, a2U);
       }
       d = dn;
       a0 = an;
     }
 
+    R acc1[7] = {a1rxy.x, a1rxy.y, a1rz, a1pxy.x, a1pxy.y, a1pz, a1U};
+    R acc2[7] = {a2rxy.x, a2rxy.y, a2rz, a2pxy.x, a2pxy.y, a2pz, a2U};
     sums[S_R1] += (double)acc1[0]; sums[S_R2] += (double)acc1[1]; sums[S_R3] += (double)acc1[2];
     sums[S_P1] += (double)acc1[3]; sums[S_P2] += (double)acc1[4]; sums[S_P3] += (double)acc1[5];
     sums[S_U] += (double)acc1[6];
@@ -296,8 +340,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     sums[S_USQ] += (double)acc2[6];
     wnorm += (double)accw;
     step += chunk;
-    remaining -= chunk;
-    steps_seg += (int)chunk;
+    left -= chunk;
+    steps_seg += chunk;
 
     // ---- step-size adaptation, mcmc_eap_chain.jl:301-322 (per chain, in f64 like the reference)
     if (A.adaptive) {
@@ -333,9 +377,10 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
   S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
   S.nacc_total[c] += nacc_seg;
-  S.obs[OBS_R1 * C + c] = O[0]; S.obs[OBS_R2 * C + c] = O[1]; S.obs[OBS_R3 * C + c] = O[2];
-  S.obs[OBS_P1 * C + c] = O[3]; S.obs[OBS_P2 * C + c] = O[4]; S.obs[OBS_P3 * C + c] = O[5];
-  S.obs[OBS_U * C + c] = O[6]; S.obs[OBS_USUM * C + c] = usum;
+  S.obs[OBS_R1 * C + c] = Orxy.x; S.obs[OBS_R2 * C + c] = Orxy.y; S.obs[OBS_R3 * C + c] = Orz;
+  S.obs[OBS_P1 * C + c] = Opxy.x; S.obs[OBS_P2 * C + c] = Opxy.y; S.obs[OBS_P3 * C + c] = Opz;
+  S.obs[OBS_U * C + c] = OU;
+  if constexpr (RARE) S.obs[OBS_USUM * C + c] = usum;   // only the umbrella weights ever read it
   if constexpr (RARE) {
     S.lag[c] = lag;
     if (umb) S.wnorm[c] = wnorm;

@@ -114,6 +114,13 @@ template <typename R> __device__ __forceinline__ R store_theta(double u) { // th
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+// {old, new} pairs: in f32 they map onto the packed VALU ops (v_pk_mul/add/fma_f32) with no shuffles
+template <typename R> struct V2;
+template <> struct V2<float> { using type = v2f; };
+template <> struct V2<double> { using type = v2d; };
+__device__ __forceinline__ v2f pfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2d pfma(v2d a, v2d b, v2d c) { return a * b + c; }  // unfused, like the oracle
 
 // Angle representation per arithmetic type.
 //   f64: radians, exactly the reference's variables (bit-reproduces the CPU oracle).
