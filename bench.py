@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
     ap.add_argument("--mc-steps", type=int, default=100000, help="MC steps per chain per bench step")
     ap.add_argument("--n", type=int, default=100)
-    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--precision", choices=["f32", "f64", "q16"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank")
     args = ap.parse_args()
@@ -121,7 +121,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    prec = ps.F64 if args.precision == "f64" else ps.F32
+    prec = {"f32": ps.F32, "f64": ps.F64, "q16": ps.Q16}[args.precision]
     stream = torch.cuda.Stream()
     nstep_total = args.steps + args.warmup
     red = torch.zeros(ps.NRED, dtype=torch.float64, device="cuda")
@@ -180,7 +180,7 @@ def main():
         total_updates = world * upd_per_launch * args.steps
         value = total_updates / elapsed
         mean_ms = sum(kernel_ms) / len(kernel_ms)
-        bytes_per_update = 32 if prec == ps.F64 else 16
+        bytes_per_update = {ps.F32: 16, ps.F64: 32, ps.Q16: 8}[prec]   # one state cell read + written
         achieved = bytes_per_update * upd_per_launch / (mean_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -198,7 +198,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 state+transcendentals, f64 running sums" if prec == ps.F32 else "f64",
+            "dtype": {ps.F32: "f32 state+transcendentals, f64 running sums", ps.F64: "f64",
+                      ps.Q16: "u16 lattice angles, f32 transcendentals, f64 running sums"}[prec],
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: non-interacting dielectric chain, n=%d, E0=1, K1=1, K2=0, "
                                    "kT=1, b=1, Fz sweep (one point per step), %d chains/GPU x %d MC steps"

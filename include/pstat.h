@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PSTAT_ABI_VERSION 1
+#define PSTAT_ABI_VERSION 2
 
 typedef enum pstat_status {
   PSTAT_OK = 0,
@@ -44,9 +44,17 @@ typedef enum pstat_status {
 enum { PSTAT_DIELECTRIC = 0, PSTAT_POLAR = 1 };
 /* --energy-type (mcmc_eap_chain.jl:41-44; inc/eap_chain.jl:95-105) */
 enum { PSTAT_NONINTERACTING = 0, PSTAT_INTERACTING = 1, PSTAT_ISING = 2 };
-/* arithmetic of the device path: f32 state and transcendentals with f64 running sums, or f64
- * throughout (the reference's Float64; bit-reproduces the CPU oracle's trajectory) */
-enum { PSTAT_F32 = 0, PSTAT_F64 = 1 };
+/* arithmetic of the device path:
+ *   PSTAT_F32  f32 state and transcendentals, f64 running sums (default);
+ *   PSTAT_F64  f64 throughout (the reference's Float64; bit-reproduces the CPU oracle's trajectory);
+ *   PSTAT_Q16  opt-in: both angles live on a 2^16-point midpoint lattice (4 bytes of state per
+ *              monomer, twice the chains resident per CU), f32 arithmetic, f64 running sums.
+ *              Discretisation bias of ensemble averages: O(h^2) ~ 1e-10. */
+enum { PSTAT_F32 = 0, PSTAT_F64 = 1, PSTAT_Q16 = 2 };
+/* per-chain generator (the reference uses Julia's unseeded default RNG; ours are seeded):
+ *   PSTAT_RNG_MWC64X        multiply-with-carry MWC64X, streams split by 2^40-output skip-ahead (default)
+ *   PSTAT_RNG_XOSHIRO128PP  xoshiro128++ seeded per chain through Philox4x32-10 */
+enum { PSTAT_RNG_MWC64X = 0, PSTAT_RNG_XOSHIRO128PP = 1 };
 
 /* Flattened pargs::Dict (mcmc_eap_chain.jl:155) -- the keys the force-ensemble step loop reads. */
 typedef struct pstat_params {
@@ -64,8 +72,10 @@ typedef struct pstat_params {
   int32_t energy_type;   /* PSTAT_NONINTERACTING | PSTAT_INTERACTING | PSTAT_ISING            */
   int32_t do_flips;      /* --do-flips                                                        */
   int32_t umbrella;      /* --umbrella-sampling                                               */
-  int32_t precision;     /* PSTAT_F32 | PSTAT_F64                                             */
+  int32_t precision;     /* PSTAT_F32 | PSTAT_F64 | PSTAT_Q16                                 */
   int32_t device;        /* HIP device ordinal                                                */
+  int32_t rng;           /* PSTAT_RNG_MWC64X | PSTAT_RNG_XOSHIRO128PP                         */
+  int32_t reserved;      /* must be 0                                                         */
 } pstat_params;
 
 /* Order of every 16-vector below = the columns of <prefix>_rolling.csv after "step"

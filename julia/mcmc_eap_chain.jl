@@ -22,6 +22,7 @@ struct PstatParams
   steps_per_adjust::Int64; n::Int64; num_chains::Int64
   seed::UInt64; chain_id0::UInt64
   chain_type::Int32; energy_type::Int32; do_flips::Int32; umbrella::Int32; precision::Int32; device::Int32
+  rng::Int32; reserved::Int32
 end
 
 # mirror of `pstat_summary`
@@ -80,6 +81,7 @@ s = ArgParseSettings();
   "--seed";                arg_type = Int;     default = 0
   "--devices";             arg_type = String;  default = "0"
   "--precision";           arg_type = String;  default = "f32"
+  "--rng";                 arg_type = String;  default = "mwc64x"
 end
 
 pargs = parse_args(s);
@@ -99,13 +101,15 @@ function params(pargs, num_chains, chain_id0, device)
   ct >= 0 || error("chain-type is not understood.")
   et = get(Dict("noninteracting" => 0, "interacting" => 1, "Ising" => 2), pargs["energy-type"], -1)
   et >= 0 || error("energy-type is not understood.")
-  prec = get(Dict("f32" => 0, "f64" => 1), pargs["precision"], -1)
+  prec = get(Dict("f32" => 0, "f64" => 1, "q16" => 2), pargs["precision"], -1)
   prec >= 0 || error("precision '$(pargs["precision"])' not understood")
+  rng = get(Dict("mwc64x" => 0, "xoshiro128++" => 1), pargs["rng"], -1)
+  rng >= 0 || error("rng '$(pargs["rng"])' not understood")
   PstatParams(pargs["E0"], pargs["K1"], pargs["K2"], pargs["mu"], pargs["kT"], pargs["Fz"], pargs["Fx"],
               pargs["mlen"], pargs["phi-step"], pargs["theta-step"], pargs["step-adjust-lb"],
               pargs["step-adjust-ub"], pargs["step-adjust-scale"], pargs["steps-per-adjust"],
               pargs["num-monomers"], num_chains, UInt64(pargs["seed"]), UInt64(chain_id0),
-              ct, et, pargs["do-flips"] ? 1 : 0, pargs["umbrella-sampling"] ? 1 : 0, prec, device)
+              ct, et, pargs["do-flips"] ? 1 : 0, pargs["umbrella-sampling"] ? 1 : 0, prec, device, rng, 0)
 end
 
 function pooled_summary(handles, steps)

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(HERE, "liboracle.so")
 
 DIELECTRIC, POLAR = 0, 1
 NONINTERACTING, INTERACTING, ISING = 0, 1, 2
+RNG_MWC64X, RNG_XOSHIRO128PP = 0, 1
 NOBS = 16
 OBS_NAMES = ["r1", "r2", "r3", "r1sq", "r2sq", "r3sq", "rsq",
              "p1", "p2", "p3", "p1sq", "p2sq", "p3sq", "psq", "U", "Usq"]
@@ -30,7 +31,7 @@ class EapParams(C.Structure):
                 ("n", "num_steps", "num_inits", "steps_per_adjust", "stepout")] + \
                [("seed", C.c_uint64)] + \
                [(k, C.c_int32) for k in
-                ("chain_type", "energy_type", "do_flips", "force_init", "umbrella", "reserved")]
+                ("chain_type", "energy_type", "do_flips", "force_init", "umbrella", "rng")]
 
 
 class EapResult(C.Structure):
@@ -68,6 +69,11 @@ def lib():
         L.eap_rng_seed.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
         L.eap_xoshiro128pp_next.argtypes = [C.POINTER(C.c_uint32)]
         L.eap_xoshiro128pp_next.restype = C.c_uint32
+        L.eap_mwc64x_seed.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+        L.eap_mwc64x_next.argtypes = [C.POINTER(C.c_uint32)]
+        L.eap_mwc64x_next.restype = C.c_uint32
+        L.eap_mwc64x_skip.argtypes = [C.c_uint64, C.c_uint64]
+        L.eap_mwc64x_skip.restype = C.c_uint64
         L.eap_u01.argtypes = [C.c_uint32]
         L.eap_u01.restype = C.c_double
         for f in (L.eap_run_faithful, L.eap_run_fast):
@@ -92,7 +98,7 @@ def make_params(**kw) -> EapParams:
              adj_lb=0.15, adj_ub=0.55, adj_scale=1.1,
              n=100, num_steps=100000, num_inits=1, steps_per_adjust=2500, stepout=500,
              seed=0, chain_type=DIELECTRIC, energy_type=NONINTERACTING,
-             do_flips=0, force_init=0, umbrella=0, reserved=0)
+             do_flips=0, force_init=0, umbrella=0, rng=RNG_MWC64X)
     unknown = set(kw) - set(d)
     if unknown:
         raise KeyError(f"unknown oracle parameter(s): {sorted(unknown)}")
@@ -193,6 +199,13 @@ def xoshiro_stream(seed: int, chain_id: int, count: int):
     lib().eap_rng_seed(seed, chain_id, s)
     init = list(s)
     return init, [lib().eap_xoshiro128pp_next(s) for _ in range(count)]
+
+
+def mwc64x_stream(seed: int, chain_id: int, count: int):
+    s = (C.c_uint32 * 4)()
+    lib().eap_mwc64x_seed(seed, chain_id, s)
+    init = (s[0], s[1])
+    return init, [lib().eap_mwc64x_next(s) for _ in range(count)]
 
 
 def pair_energy(xs: np.ndarray, mus: np.ndarray, ising: bool = False) -> float:

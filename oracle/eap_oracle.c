@@ -11,7 +11,12 @@
  *                      with an O(1) energy difference; this is the form the HIP kernels use.
  *
  * Random stream contract (ours; the reference is unseeded, mcmc_eap_chain.jl has no seed):
- *   state   = xoshiro128++ seeded with Philox4x32-10(key = seed, ctr = (chain_lo, chain_hi, 0x5eed, 0))
+ *   generator, one per chain (eap_params.rng):
+ *     EAP_RNG_MWC64X       MWC64X (D. Thomas): out = x ^ c; (c:x) <- A*x + c, A = 4294883355.  All chains
+ *                          of a run walk one sequence; chain k starts k * 2^40 outputs after the base
+ *                          state 1 + Philox4x32-10(key = seed, ctr = (0,0,0x5eed,1))[0:1] mod (M - 2),
+ *                          M = A*2^32 - 1 (skip-ahead: state * A^(k 2^40) mod M)
+ *     EAP_RNG_XOSHIRO128PP xoshiro128++ seeded with Philox4x32-10(key = seed, ctr = (chain_lo, chain_hi, 0x5eed, 0))
  *   u(w)    = (w >> 9) * 2^-23   (23 bits: exactly the f32 mantissa trick the kernels use)
  *   init    : phi_i = 2pi*u  for i = 1..n, then theta_i = pi*u for i = 1..n   (eap_chain.jl:6-7,61-62)
  *   step    : idx = mulhi32(w, n); dphi = phi_step*(2u-1); [flip bit = w>>31 if --do-flips];
@@ -71,11 +76,57 @@ uint32_t eap_xoshiro128pp_next(uint32_t s[4]) {
   return result;
 }
 
+/* MWC64X, David B. Thomas, "The MWC64X random number generator" (2011).  As an LCG:
+ * s' = A s mod M with s = c 2^32 + x and M = A 2^32 - 1, which gives exact skip-ahead. */
+#define MWC_A 4294883355u
+#define MWC_M 0xFFFEB81AFFFFFFFFull
+
+static uint64_t mwc_mulmod(uint64_t a, uint64_t b) {
+  return (uint64_t)(((unsigned __int128)a * b) % MWC_M);
+}
+static uint64_t mwc_powmod(uint64_t g, uint64_t e) {
+  uint64_t r = 1;
+  for (; e; e >>= 1, g = mwc_mulmod(g, g))
+    if (e & 1) r = mwc_mulmod(r, g);
+  return r;
+}
+uint64_t eap_mwc64x_skip(uint64_t state, uint64_t nsteps) {
+  return mwc_mulmod(state, mwc_powmod(MWC_A, nsteps));
+}
+void eap_mwc64x_seed(uint64_t seed, uint64_t chain_id, uint32_t s[4]) {
+  uint32_t ctr[4] = {0u, 0u, 0x5eedu, 1u};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t o[4];
+  eap_philox4x32_10(ctr, key, o);
+  uint64_t v = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+  uint64_t base = 1 + v % (MWC_M - 2);
+  /* chain k starts k * 2^40 outputs down the sequence: A^(k 2^40) = (A^(2^40))^k */
+  uint64_t g40 = mwc_powmod(MWC_A, 1ull << 40);
+  uint64_t st = mwc_mulmod(base, mwc_powmod(g40, chain_id));
+  s[0] = (uint32_t)st; s[1] = (uint32_t)(st >> 32); s[2] = 0u; s[3] = 0u;
+}
+uint32_t eap_mwc64x_next(uint32_t s[4]) {
+  uint32_t r = s[0] ^ s[1];
+  uint64_t t = (uint64_t)s[0] * MWC_A + s[1];
+  s[0] = (uint32_t)t; s[1] = (uint32_t)(t >> 32);
+  return r;
+}
+
 double eap_u01(uint32_t w) { return (double)(w >> 9) * (1.0 / 8388608.0); }
 
-static inline double draw_u(uint32_t s[4]) { return eap_u01(eap_xoshiro128pp_next(s)); }
-static inline int64_t draw_idx(uint32_t s[4], int64_t n) {
-  return (int64_t)(((uint64_t)eap_xoshiro128pp_next(s) * (uint64_t)n) >> 32);
+/* generator state: s[0..3] + the kind in s[4] (kept beside the state so every draw site stays a
+ * one-liner) */
+static inline uint32_t draw_w(uint32_t s[5]) {
+  return s[4] == EAP_RNG_XOSHIRO128PP ? eap_xoshiro128pp_next(s) : eap_mwc64x_next(s);
+}
+static inline double draw_u(uint32_t s[5]) { return eap_u01(draw_w(s)); }
+static inline int64_t draw_idx(uint32_t s[5], int64_t n) {
+  return (int64_t)(((uint64_t)draw_w(s) * (uint64_t)n) >> 32);
+}
+static void seed_chain(const eap_params *P, uint64_t chain_id, uint32_t s[5]) {
+  s[4] = (uint32_t)P->rng;
+  if (P->rng == EAP_RNG_XOSHIRO128PP) eap_rng_seed(P->seed, chain_id, s);
+  else eap_mwc64x_seed(P->seed, chain_id, s);
 }
 
 /* ------------------------------------------------------------------ physics pieces */
@@ -223,7 +274,7 @@ static void chain_derive(const eap_params *P, chain_t *c) {
 }
 
 /* EAPChain(pargs), eap_chain.jl:60-135: all phi draws, then all theta draws */
-static void chain_random(const eap_params *P, uint32_t rng[4], chain_t *c) {
+static void chain_random(const eap_params *P, uint32_t rng[5], chain_t *c) {
   for (int64_t i = 0; i < c->n; ++i) c->phi[i] = (2.0 * M_PI) * draw_u(rng);
   for (int64_t i = 0; i < c->n; ++i) c->th[i] = M_PI * draw_u(rng);
   chain_derive(P, c);
@@ -324,6 +375,7 @@ static int check_params(const eap_params *P) {
   if (P->n < 1 || P->num_steps < 0 || P->num_inits < 1) return -1;
   if (P->chain_type != EAP_DIELECTRIC && P->chain_type != EAP_POLAR) return -1;
   if (P->energy_type < 0 || P->energy_type > EAP_ISING) return -1;
+  if (P->rng != EAP_RNG_MWC64X && P->rng != EAP_RNG_XOSHIRO128PP) return -1;
   return 0;
 }
 
@@ -331,8 +383,8 @@ static int check_params(const eap_params *P) {
 
 int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, eap_trace *tr) {
   if (check_params(P)) return -1;
-  uint32_t rng[4];
-  eap_rng_seed(P->seed, chain_id, rng);
+  uint32_t rng[5];
+  seed_chain(P, chain_id, rng);
   chain_t cur, trial, fresh;
   if (chain_alloc(&cur, P->n) || chain_alloc(&trial, P->n) || chain_alloc(&fresh, P->n)) return -2;
   if (tr) tr->rows_written = 0;
@@ -352,7 +404,7 @@ int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, ea
       int64_t idx = draw_idx(rng, P->n);                        /* :277 */
       double dphi = phistep * (2.0 * draw_u(rng) - 1.0);        /* :278 */
       double flip = 0.0;
-      if (P->do_flips && (eap_xoshiro128pp_next(rng) >> 31))    /* :279 */
+      if (P->do_flips && (draw_w(rng) >> 31))                   /* :279 */
         flip = M_PI - 2 * cur.th[idx];
       double dth = flip + thstep * (2.0 * draw_u(rng) - 1.0);   /* :280 */
       chain_copy(&trial, &cur);                                 /* :281 */
@@ -398,7 +450,7 @@ int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, ea
   memcpy(out->r, cur.r, sizeof cur.r);
   chain_mu(&cur, out->p);
   out->U = cur.U;
-  memcpy(out->rng, rng, sizeof out->rng);
+  memcpy(out->rng, rng, sizeof out->rng);  /* the four state words */
   if (tr && tr->final_phi) memcpy(tr->final_phi, cur.phi, sizeof(double) * (size_t)P->n);
   if (tr && tr->final_theta) memcpy(tr->final_theta, cur.th, sizeof(double) * (size_t)P->n);
   chain_free(&cur); chain_free(&trial); chain_free(&fresh);
@@ -466,7 +518,7 @@ static void fast_derive(const eap_params *P, fast_t *c, double *Omega) {
   if (Omega) *Omega = log(prod);
 }
 
-static void fast_random(const eap_params *P, uint32_t rng[4], fast_t *c, double *Omega) {
+static void fast_random(const eap_params *P, uint32_t rng[5], fast_t *c, double *Omega) {
   for (int64_t i = 0; i < c->n; ++i) c->phi[i] = (2.0 * M_PI) * draw_u(rng);
   for (int64_t i = 0; i < c->n; ++i) c->th[i] = M_PI * draw_u(rng);
   fast_derive(P, c, Omega);
@@ -491,8 +543,8 @@ static double ising_bonds(const eap_params *P, const fast_t *c, int64_t idx, con
 
 int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_trace *tr) {
   if (check_params(P)) return -1;
-  uint32_t rng[4];
-  eap_rng_seed(P->seed, chain_id, rng);
+  uint32_t rng[5];
+  seed_chain(P, chain_id, rng);
   fast_t c, fresh;
   if (fast_alloc(&c, P->n) || fast_alloc(&fresh, P->n)) return -2;
   double *xs_backup = (double *)malloc(sizeof(double) * (size_t)(6 * P->n)); /* xs then cs */
@@ -514,7 +566,7 @@ int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_tr
       int64_t idx = draw_idx(rng, P->n);
       double dphi = phistep * (2.0 * draw_u(rng) - 1.0);
       double flip = 0.0;
-      if (P->do_flips && (eap_xoshiro128pp_next(rng) >> 31)) flip = M_PI - 2 * c.th[idx];
+      if (P->do_flips && (draw_w(rng) >> 31)) flip = M_PI - 2 * c.th[idx];
       double dth = flip + thstep * (2.0 * draw_u(rng) - 1.0);
       double eps = draw_u(rng);
 
@@ -589,7 +641,7 @@ int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_tr
   out->phi_step = phistep; out->theta_step = thstep;
   memcpy(out->r, c.r, sizeof c.r); memcpy(out->p, c.p, sizeof c.p);
   out->U = c.U;
-  memcpy(out->rng, rng, sizeof out->rng);
+  memcpy(out->rng, rng, sizeof out->rng);  /* the four state words */
   if (tr && tr->final_phi) memcpy(tr->final_phi, c.phi, sizeof(double) * (size_t)P->n);
   if (tr && tr->final_theta) memcpy(tr->final_theta, c.th, sizeof(double) * (size_t)P->n);
   free(c.block); free(fresh.block); free(xs_backup);

@@ -26,6 +26,7 @@ extern "C" {
 
 enum { EAP_DIELECTRIC = 0, EAP_POLAR = 1 };              /* --chain-type  */
 enum { EAP_NONINTERACTING = 0, EAP_INTERACTING = 1, EAP_ISING = 2 }; /* --energy-type */
+enum { EAP_RNG_MWC64X = 0, EAP_RNG_XOSHIRO128PP = 1 };               /* per-chain generator */
 
 /* Flat mirror of the option table mcmc_eap_chain.jl:19-153 (hot-path subset). */
 typedef struct eap_params {
@@ -43,7 +44,7 @@ typedef struct eap_params {
   int32_t do_flips;
   int32_t force_init;
   int32_t umbrella;
-  int32_t reserved;
+  int32_t rng;          /* EAP_RNG_MWC64X | EAP_RNG_XOSHIRO128PP */
 } eap_params;
 
 /* Index order = the rolling.csv columns after "step" (mcmc_eap_chain.jl:259). */
@@ -76,8 +77,11 @@ typedef struct eap_trace {
 
 /* --- random stream contract (shared with the HIP path by specification) --- */
 void eap_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-void eap_rng_seed(uint64_t seed, uint64_t chain_id, uint32_t s[4]);
+void eap_rng_seed(uint64_t seed, uint64_t chain_id, uint32_t s[4]);   /* xoshiro128++ state */
 uint32_t eap_xoshiro128pp_next(uint32_t s[4]);
+void eap_mwc64x_seed(uint64_t seed, uint64_t chain_id, uint32_t s[4]); /* s[0] = x, s[1] = c */
+uint32_t eap_mwc64x_next(uint32_t s[4]);
+uint64_t eap_mwc64x_skip(uint64_t state, uint64_t nsteps);             /* state = c*2^32 + x */
 double eap_u01(uint32_t w);                       /* (w>>9) * 2^-23 in [0,1) */
 
 /* --- the two restatements --- */

@@ -10,7 +10,8 @@ LIB_PATH = os.path.join(HERE, "libpstat.so")
 
 DIELECTRIC, POLAR = 0, 1
 NONINTERACTING, INTERACTING, ISING = 0, 1, 2
-F32, F64 = 0, 1
+F32, F64, Q16 = 0, 1, 2
+RNG_MWC64X, RNG_XOSHIRO128PP = 0, 1
 NOBS = 16
 NRED = 35
 OBS_NAMES = ["r1", "r2", "r3", "r1sq", "r2sq", "r3sq", "rsq",
@@ -39,7 +40,7 @@ class Params(C.Structure):
                [("steps_per_adjust", C.c_int64), ("n", C.c_int64), ("num_chains", C.c_int64),
                 ("seed", C.c_uint64), ("chain_id0", C.c_uint64)] + \
                [(k, C.c_int32) for k in
-                ("chain_type", "energy_type", "do_flips", "umbrella", "precision", "device")]
+                ("chain_type", "energy_type", "do_flips", "umbrella", "precision", "device", "rng", "reserved")]
 
 
 class Summary(C.Structure):

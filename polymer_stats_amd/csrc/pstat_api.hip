@@ -89,8 +89,13 @@ int validate(const pstat_params *c, int ncases) {
                 "num-monomers must be <= 64 (got %lld)", (long long)b.n);
   if (b.umbrella && b.energy_type == PSTAT_INTERACTING)
     return fail(PSTAT_ERR_UNSUPPORTED, "umbrella sampling is not implemented for energy-type 'interacting'");
-  if (b.precision != PSTAT_F32 && b.precision != PSTAT_F64)
-    return fail(PSTAT_ERR_INVALID_ARG, "precision must be PSTAT_F32 or PSTAT_F64");
+  if (b.precision != PSTAT_F32 && b.precision != PSTAT_F64 && b.precision != PSTAT_Q16)
+    return fail(PSTAT_ERR_INVALID_ARG, "precision must be PSTAT_F32, PSTAT_F64 or PSTAT_Q16");
+  if (b.precision == PSTAT_Q16 && b.energy_type == PSTAT_INTERACTING)
+    return fail(PSTAT_ERR_UNSUPPORTED, "the lattice state (PSTAT_Q16) is not implemented for energy-type 'interacting'");
+  if (b.rng != PSTAT_RNG_MWC64X && b.rng != PSTAT_RNG_XOSHIRO128PP)
+    return fail(PSTAT_ERR_INVALID_ARG, "rng must be PSTAT_RNG_MWC64X or PSTAT_RNG_XOSHIRO128PP");
+  if (b.reserved != 0) return fail(PSTAT_ERR_INVALID_ARG, "reserved field must be 0");
   if (!(b.phi_step > 0) || !(b.theta_step > 0))
     return fail(PSTAT_ERR_INVALID_ARG, "phi-step and theta-step must be > 0");
   if (!(b.adj_scale > 0)) return fail(PSTAT_ERR_INVALID_ARG, "step-adjust-scale must be > 0");
@@ -102,7 +107,7 @@ int validate(const pstat_params *c, int ncases) {
       return fail(PSTAT_ERR_INVALID_ARG, "non-finite physics parameter (case %d)", i);
     if (p.n != b.n || p.num_chains != b.num_chains || p.chain_type != b.chain_type ||
         p.energy_type != b.energy_type || p.do_flips != b.do_flips || p.umbrella != b.umbrella ||
-        p.precision != b.precision || p.device != b.device || p.phi_step != b.phi_step ||
+        p.precision != b.precision || p.device != b.device || p.rng != b.rng || p.phi_step != b.phi_step ||
         p.theta_step != b.theta_step || p.adj_lb != b.adj_lb || p.adj_ub != b.adj_ub ||
         p.adj_scale != b.adj_scale || p.steps_per_adjust != b.steps_per_adjust)
       return fail(PSTAT_ERR_INVALID_ARG, "case %d differs from case 0 in a non-physics field", i);
@@ -172,6 +177,7 @@ void pstat_default_params(pstat_params *p) {
   p->chain_type = PSTAT_DIELECTRIC; p->energy_type = PSTAT_NONINTERACTING;
   p->do_flips = 0; p->umbrella = 0;
   p->precision = PSTAT_F32; p->device = 0;
+  p->rng = PSTAT_RNG_MWC64X; p->reserved = 0;
 }
 
 int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_handle **out) {
@@ -189,7 +195,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   h->base = cases[0];
   h->ncases = ncases;
   h->device = cases[0].device;
-  h->elem = cases[0].precision == PSTAT_F64 ? 8 : 4;
+  h->elem = cases[0].precision == PSTAT_F64 ? 8 : (cases[0].precision == PSTAT_Q16 ? 2 : 4);
   for (int i = 0; i < ncases; ++i) {
     const pstat_params &p = cases[i];
     h->cases.push_back({p.E0, p.K1, p.K2, p.mu, p.kT, p.Fz, p.Fx, p.b, p.seed, p.chain_id0});
@@ -197,7 +203,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   bool any_fx = false;
   for (auto &c : h->cases) any_fx = any_fx || c.Fx != 0.0;
   h->cfg = {h->base.precision, h->base.chain_type, h->base.energy_type, h->base.do_flips ? 1 : 0,
-            h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, trig_mode_from_env()};
+            h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, trig_mode_from_env(), 0, h->base.rng};
 
   const bool inter = h->base.energy_type == PSTAT_INTERACTING;
   int lanes = inter ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
@@ -472,10 +478,14 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sum
     std::vector<unsigned char> tmp(2 * n * h->elem);
     HIP_TRY(hipMemcpy2D(tmp.data(), h->elem, (char *)h->S.ang + (size_t)chain * h->elem, C * h->elem,
                         h->elem, 2 * n, hipMemcpyDeviceToHost));
-    // f32 handles store angles in turns (pstat_kernels.hip, Ang<float>); the ABI speaks radians
-    for (size_t i = 0; i < 2 * n; ++i)
-      angles[i] = h->elem == 8 ? ((double *)tmp.data())[i]
-                               : (double)((float *)tmp.data())[i] * 6.28318530717958647692;
+    // storage formats: pstat_math.h (radians | turns | lattice index); the ABI speaks radians
+    for (size_t i = 0; i < 2 * n; ++i) {
+      const bool is_theta = i < n;
+      if (h->elem == 8) angles[i] = ((double *)tmp.data())[i];
+      else if (h->elem == 4) angles[i] = (double)((float *)tmp.data())[i] * 6.28318530717958647692;
+      else angles[i] = (is_theta ? 3.14159265358979323846 : 6.28318530717958647692) *
+                       ((double)((uint16_t *)tmp.data())[i] + 0.5) / 65536.0;
+    }
   }
   if (sums) {
     double s[NSUMS];

@@ -57,9 +57,20 @@ struct SweepArgs {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Random stream contract (restated, not shared, in oracle/eap_oracle.c):
-//   xoshiro128++ seeded by Philox4x32-10(key = seed, ctr = (chain_lo, chain_hi, 0x5eed, 0));
-//   u(w) = (w >> 9) * 2^-23;  idx = mulhi32(w, n).
+// Random stream contract (restated, not shared, in oracle/eap_oracle.c).  Two generators:
+//
+//  PSTAT_RNG_MWC64X (default): D. Thomas' MWC64X multiply-with-carry, state (x, c) 32+32 bits,
+//      out = x ^ c;  (c:x) <- A * x + c,  A = 4294883355,  period ~2^63, passes TestU01 BigCrush.
+//      One v_mad_u64_u32 + one v_xor per output: measured 125 cycles per MC step (4 outputs) for a
+//      lone wave against 226 for xoshiro128++ (tools/ubench).  As an LCG it is s <- A*s mod M with
+//      s = c*2^32 + x, M = A*2^32 - 1, so streams are split by SKIP-AHEAD: all chains of a run walk
+//      ONE sequence, chain id k starting k * 2^40 outputs after the seed-selected base state
+//      (s_k = s_base * G^k mod M, G = A^(2^40) mod M): disjoint by construction for 2^40 outputs
+//      (~2.7e11 MC steps) per chain.  The base state comes from Philox4x32-10(key = seed).
+//  PSTAT_RNG_XOSHIRO128PP: xoshiro128++ seeded per chain by Philox4x32-10(key = seed,
+//      ctr = (chain_lo, chain_hi, 0x5eed, 0)).
+//
+//  u(w) = (w >> 9) * 2^-23;  idx = mulhi32(w, n).
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -95,12 +106,67 @@ struct Xoshiro128pp {
     s3 = (s3 << 11) | (s3 >> 21);
     return result;
   }
+  __host__ __device__ inline void load(const uint32_t *p, int64_t stride) {
+    s0 = p[0]; s1 = p[stride]; s2 = p[2 * stride]; s3 = p[3 * stride];
+  }
+  __host__ __device__ inline void store(uint32_t *p, int64_t stride) const {
+    p[0] = s0; p[stride] = s1; p[2 * stride] = s2; p[3 * stride] = s3;
+  }
+};
+
+struct Mwc64x {
+  static constexpr uint32_t A = 4294883355u;
+  static constexpr uint64_t M = 0xFFFEB81AFFFFFFFFull;   // A * 2^32 - 1
+  static constexpr uint64_t G40 = 0x82A211110E454078ull; // A^(2^40) mod M
+  uint32_t x, c;
+  __host__ __device__ static inline uint64_t addmod(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;                       // a, b < M < 2^64
+    if (s < a || s >= M) s -= M;              // on wrap-around the true sum is s + 2^64
+    return s;
+  }
+  __host__ __device__ static inline uint64_t mulmod(uint64_t a, uint64_t b) {
+    uint64_t r = 0;
+    while (b) {
+      if (b & 1) r = addmod(r, a);
+      a = addmod(a, a);
+      b >>= 1;
+    }
+    return r;
+  }
+  __host__ __device__ static inline uint64_t powmod(uint64_t g, uint64_t e) {
+    uint64_t r = 1;
+    while (e) {
+      if (e & 1) r = mulmod(r, g);
+      g = mulmod(g, g);
+      e >>= 1;
+    }
+    return r;
+  }
+  __host__ __device__ inline void seed(uint64_t seed, uint64_t chain_id) {
+    uint32_t o[4];
+    philox4x32_10(0u, 0u, 0x5eedu, 1u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const uint64_t v = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+    const uint64_t base = 1 + v % (M - 2);                 // in [1, M-2]
+    const uint64_t s = mulmod(base, powmod(G40, chain_id));
+    x = (uint32_t)s; c = (uint32_t)(s >> 32);
+  }
+  __host__ __device__ inline uint32_t next() {
+    const uint32_t r = x ^ c;
+    const uint64_t t = (uint64_t)x * A + c;
+    x = (uint32_t)t; c = (uint32_t)(t >> 32);
+    return r;
+  }
+  __host__ __device__ inline void load(const uint32_t *p, int64_t stride) { x = p[0]; c = p[stride]; }
+  __host__ __device__ inline void store(uint32_t *p, int64_t stride) const {
+    p[0] = x; p[stride] = c; p[2 * stride] = 0u; p[3 * stride] = 0u;
+  }
 };
 
 // host-callable launchers implemented in pstat_kernels.hip; all asynchronous on `stream`
 struct LaunchCfg {
   int precision, chain_type, energy_type, do_flips, umbrella, has_fx, trig_mode;
   int lag;  // a re-init has happened on this handle
+  int rng;  // PSTAT_RNG_MWC64X | PSTAT_RNG_XOSHIRO128PP
 };
 hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                        const CaseConst *cases, double phi_step, double theta_step,

@@ -90,7 +90,7 @@ __device__ __forceinline__ double pair_fast(double rx, double ry, double rz, dou
   return pair_term<double>(rx, ry, rz, mix, miy, miz, mjx, mjy, mjz);
 }
 
-template <typename R, int CT, int TRIG>
+template <typename R, typename G, int CT, int TRIG>
 __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S,
                                                          const CaseConst *__restrict__ cases,
                                                          int do_flips, int use_lag) {
@@ -115,11 +115,12 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
   const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
   R th = real ? gth[(int64_t)lane * C + c] : (R)0;
   R ph = real ? gph[(int64_t)lane * C + c] : (R)0;
-  Xoshiro128pp g;
-  g.s0 = __builtin_amdgcn_readfirstlane(S.rng[0 * C + c]);
-  g.s1 = __builtin_amdgcn_readfirstlane(S.rng[1 * C + c]);
-  g.s2 = __builtin_amdgcn_readfirstlane(S.rng[2 * C + c]);
-  g.s3 = __builtin_amdgcn_readfirstlane(S.rng[3 * C + c]);
+  G g;   // wave-uniform: one stream per chain, kept in SGPRs
+  {
+    uint32_t w[4];
+    for (int q = 0; q < 4; ++q) w[q] = __builtin_amdgcn_readfirstlane(S.rng[q * C + c]);
+    g.load(w, 1);
+  }
   double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
   R phistep = (R)(phistep_d / AG::unit), thstep = (R)(thstep_d / AG::unit);
   int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
     wph[(int64_t)lane * C + c] = ph;
   }
   if (lane == 0) {
-    S.rng[0 * C + c] = g.s0; S.rng[1 * C + c] = g.s1; S.rng[2 * C + c] = g.s2; S.rng[3 * C + c] = g.s3;
+    g.store(S.rng + c, C);
     S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
     S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
     S.nacc_total[c] += nacc_seg;
@@ -302,13 +303,15 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
 
 using InterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int);
 
-static InterFn pick_interacting(const LaunchCfg &cfg) {
+template <typename G>
+static InterFn pick_interacting_g(const LaunchCfg &cfg) {
   const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
   if (cfg.precision == PSTAT_F64)
-    return diel ? interacting_kernel<double, PSTAT_DIELECTRIC, 0> : interacting_kernel<double, PSTAT_POLAR, 0>;
-  if (cfg.trig_mode == 0)
-    return diel ? interacting_kernel<float, PSTAT_DIELECTRIC, 0> : interacting_kernel<float, PSTAT_POLAR, 0>;
-  return diel ? interacting_kernel<float, PSTAT_DIELECTRIC, 1> : interacting_kernel<float, PSTAT_POLAR, 1>;
+    return diel ? interacting_kernel<double, G, PSTAT_DIELECTRIC, 0> : interacting_kernel<double, G, PSTAT_POLAR, 0>;
+  return diel ? interacting_kernel<float, G, PSTAT_DIELECTRIC, 1> : interacting_kernel<float, G, PSTAT_POLAR, 1>;
+}
+static InterFn pick_interacting(const LaunchCfg &cfg) {
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_interacting_g<Xoshiro128pp>(cfg) : pick_interacting_g<Mwc64x>(cfg);
 }
 
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,

@@ -23,6 +23,7 @@
 
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 
 #include "../../include/pstat.h"
 #include "pstat_math.h"
@@ -33,7 +34,7 @@ namespace pstat {
 
 // EAPChain(pargs), inc/eap_chain.jl:60-135: all phi draws, then all theta draws; then r, p, U.
 // One thread per chain; angles are rounded to the storage type R before anything is derived.
-template <typename R>
+template <typename R, typename G>
 __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
                             int chain_type, int energy_type, double phi_step, double theta_step) {
   int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -41,7 +42,7 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
   const int64_t icase = c / A.chains_per_case, local = c % A.chains_per_case;
   const CaseConst cc = cases[icase];
   R *th = (R *)S.ang, *ph = (R *)S.ang + A.n * S.C;
-  Xoshiro128pp g;
+  G g;
   g.seed(cc.seed, cc.chain_id0 + (uint64_t)local);
   for (int64_t i = 0; i < A.n; ++i) ph[i * S.C + c] = store_phi<R>(u01<double>(g.next()));
   for (int64_t i = 0; i < A.n; ++i) th[i * S.C + c] = store_theta<R>(u01<double>(g.next()));
@@ -49,7 +50,7 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
   double r[3] = {0, 0, 0}, p[3] = {0, 0, 0}, usum = 0, upair = 0, omega = 0;
   double pnx = 0, pny = 0, pnz = 0, pmx = 0, pmy = 0, pmz = 0;
   for (int64_t i = 0; i < A.n; ++i) {
-    double t = (double)th[i * S.C + c] * ang_unit<R>(), f = (double)ph[i * S.C + c] * ang_unit<R>();
+    double t = load_theta<R>(th[i * S.C + c]), f = load_phi<R>(ph[i * S.C + c]);
     double st = sin(t), ct = cos(t), sp = sin(f), cp = cos(f);
     double nx = cp * st, ny = sp * st, nz = ct, mx, my, mz;
     if (chain_type == PSTAT_DIELECTRIC)
@@ -70,7 +71,7 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
   S.obs[OBS_R1 * S.C + c] = r[0]; S.obs[OBS_R2 * S.C + c] = r[1]; S.obs[OBS_R3 * S.C + c] = r[2];
   S.obs[OBS_P1 * S.C + c] = p[0]; S.obs[OBS_P2 * S.C + c] = p[1]; S.obs[OBS_P3 * S.C + c] = p[2];
   S.obs[OBS_U * S.C + c] = U; S.obs[OBS_USUM * S.C + c] = usum;
-  S.rng[0 * S.C + c] = g.s0; S.rng[1 * S.C + c] = g.s1; S.rng[2 * S.C + c] = g.s2; S.rng[3 * S.C + c] = g.s3;
+  g.store(S.rng + c, S.C);
   S.stepsz[0 * S.C + c] = phi_step; S.stepsz[1 * S.C + c] = theta_step;
   S.win[0 * S.C + c] = 0; S.win[1 * S.C + c] = 0;
   S.nacc_total[c] = 0;
@@ -87,8 +88,8 @@ struct Draw {  // raw words of one step's proposal, mcmc_eap_chain.jl:277-280,28
   uint32_t idx, wphi, wth, weps, wflip;
 };
 
-template <bool RARE>
-__device__ __forceinline__ Draw draw_step(Xoshiro128pp &g, uint32_t n, bool flips) {
+template <bool RARE, typename G>
+__device__ __forceinline__ Draw draw_step(G &g, uint32_t n, bool flips) {
   Draw d;
   d.idx = __umulhi(g.next(), n);
   d.wphi = g.next();
@@ -108,13 +109,18 @@ struct SweepRare {  // wave-uniform switches of the rarely used options (RARE in
 };
 
 // One time-segment of one chain block: fill LDS/registers from HBM, run `nsteps` steps, spill.
-template <typename R, int CT, int EN, bool FX, bool RARE, int TRIG>
+template <typename R, typename G, int CT, int EN, bool FX, bool RARE, int TRIG, int ST>
 __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &S, const CaseConst &cc,
                                             const SweepRare rare, unsigned char *smem, const int lane,
                                             const int64_t c, int64_t step, int64_t remaining) {
   using R2 = typename Vec2<R>::type;
   using AG = Ang<R, TRIG>;
-  R2 *ang = reinterpret_cast<R2 *>(smem);  // [n][lanes] : .x = theta, .y = phi
+  // ST = 0: the LDS cell is the (theta, phi) pair in R.  ST = 1 (PSTAT_Q16, R = float): the cell is
+  // one 32-bit word, theta lattice index in the low half and phi index in the high half.
+  constexpr bool Q = ST == 1;
+  static_assert(!Q || sizeof(R) == 4, "the lattice state runs on f32 arithmetic");
+  using Cell = typename std::conditional<Q, uint32_t, R2>::type;
+  Cell *ang = reinterpret_cast<Cell *>(smem);  // [n][lanes]
   const int lanes = A.lanes;
   const int64_t C = S.C;
   const int n = (int)A.n;
@@ -130,7 +136,11 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   (void)Fx; (void)kT; (void)hb; (void)nbeta_log2e;
 
   // ---- fill
-  {
+  if constexpr (Q) {
+    const uint16_t *gth = (const uint16_t *)S.ang, *gph = (const uint16_t *)S.ang + (int64_t)n * C;
+    for (int i = 0; i < n; ++i)
+      ang[i * lanes + lane] = (uint32_t)gth[(int64_t)i * C + c] | ((uint32_t)gph[(int64_t)i * C + c] << 16);
+  } else {
     const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
     for (int i = 0; i < n; ++i) {
       R2 v;
@@ -139,10 +149,13 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       ang[i * lanes + lane] = v;
     }
   }
-  Xoshiro128pp g;
-  g.s0 = S.rng[0 * C + c]; g.s1 = S.rng[1 * C + c]; g.s2 = S.rng[2 * C + c]; g.s3 = S.rng[3 * C + c];
+  // step sizes in the unit the proposal is added in: radians (f64), turns (f32), lattice cells (q16)
+  constexpr double th_unit = Q ? 3.14159265358979323846 / 65536.0 : AG::unit;
+  constexpr double ph_unit = Q ? 6.28318530717958647692 / 65536.0 : AG::unit;
+  G g;
+  g.load(S.rng + c, C);
   double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
-  R phistep = (R)(phistep_d / AG::unit), thstep = (R)(thstep_d / AG::unit);
+  R phistep = (R)(phistep_d / ph_unit), thstep = (R)(thstep_d / th_unit);
   int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
   // observables O = (rx, ry | rz, px | py, pz | U, unused) as four 2-vectors (packed f32 math)
@@ -172,7 +185,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // prefetched row is replaced by the freshly accepted angles.
   using P = typename V2<R>::type;   // {old, new}
   Draw d = draw_step<RARE>(g, (uint32_t)n, flips);
-  R2 a0 = ang[d.idx * lanes + lane];
+  Cell a0 = ang[d.idx * lanes + lane];
   int left = (int)remaining;        // steps still to run in this segment (<= 2^30)
   // running observables: (rx, ry) and (px, py) as pairs, the z components and U as scalars
   P Orxy = {O[0], O[1]}, Opxy = {O[3], O[4]};
@@ -190,29 +203,46 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     for (int k = 0; k < chunk; ++k) {
       const bool more = left - k > 1;  // wave-uniform (scalar compare)
       Draw dn = d;
-      R2 an = a0;
+      Cell an = a0;
       if (more) {
         dn = draw_step<RARE>(g, (uint32_t)n, flips);
         an = ang[dn.idx * lanes + lane];
       }
-      // ---- proposal, mcmc_eap_chain.jl:277-280
-      const R th0 = a0.x, ph0 = a0.y;
-      R flip = 0;
-      if constexpr (RARE) {
-        if (flips && (d.wflip >> 31)) flip = AG::theta_max - 2 * th0;
-      }
+      // ---- proposal, mcmc_eap_chain.jl:277-280, and trial angles, inc/eap_chain.jl:232-236
       const R eps = u01<R>(d.weps);
-
-      // ---- move!, inc/eap_chain.jl:232-245 (trial values; committed by selects below)
-      R ph1, th1;
-      if constexpr (sizeof(R) == 8) {
-        const R dphi = phistep * sym11<R>(d.wphi);
-        const R dth = flip + thstep * sym11<R>(d.wth);
-        ph1 = AG::wrap(ph0 + dphi);
-        th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
+      R th0, ph0, th1, ph1;
+      bool inside = true;           // q16: the trial theta stayed on the lattice (else: clamped => rejected)
+      uint32_t cell1 = 0;           // q16: packed trial state
+      if constexpr (Q) {
+        uint32_t k0 = a0 & 0xFFFFu;
+        const uint32_t j0 = a0 >> 16;
+        th0 = q16_theta_turns(k0);
+        ph0 = q16_phi_turns(j0);
+        if constexpr (RARE) {
+          if (flips && (d.wflip >> 31)) k0 = 65535u - k0;   // theta -> pi - theta, exact on the lattice
+        }
+        const int k1 = (int)k0 + q16_disp(thstep, sym11<R>(d.wth));
+        const uint32_t j1 = (j0 + (uint32_t)q16_disp(phistep, sym11<R>(d.wphi))) & 0xFFFFu;
+        inside = (uint32_t)k1 < 65536u;   // theta' clamped to 0 or pi has sin = 0: never accepted
+        const uint32_t k1c = (uint32_t)min(max(k1, 0), 65535);
+        th1 = q16_theta_turns(k1c);
+        ph1 = q16_phi_turns(j1);
+        cell1 = k1c | (j1 << 16);
       } else {
-        ph1 = AG::wrap(fma_r(phistep, sym11<R>(d.wphi), ph0));
-        th1 = fmin(AG::theta_max, fmax((R)0, fma_r(thstep, sym11<R>(d.wth), th0 + flip)));
+        th0 = a0.x; ph0 = a0.y;
+        R flip = 0;
+        if constexpr (RARE) {
+          if (flips && (d.wflip >> 31)) flip = AG::theta_max - 2 * th0;
+        }
+        if constexpr (sizeof(R) == 8) {
+          const R dphi = phistep * sym11<R>(d.wphi);
+          const R dth = flip + thstep * sym11<R>(d.wth);
+          ph1 = AG::wrap(ph0 + dphi);
+          th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
+        } else {
+          ph1 = AG::wrap(fma_r(phistep, sym11<R>(d.wphi), ph0));
+          th1 = fmin(AG::theta_max, fmax((R)0, fma_r(thstep, sym11<R>(d.wth), th0 + flip)));
+        }
       }
       R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
       AG::sc(th0, &st0, &ct0);
@@ -249,10 +279,13 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         for (int side = -1; side <= 1; side += 2) {
           const int j = (int)d.idx + side;
           if (j >= 0 && j < n) {
-            const R2 aj = ang[j * lanes + lane];
+            const Cell aj = ang[j * lanes + lane];
+            R thj, phj;
+            if constexpr (Q) { thj = q16_theta_turns(aj & 0xFFFFu); phj = q16_phi_turns(aj >> 16); }
+            else { thj = aj.x; phj = aj.y; }
             R sj, cj, spj, cpj, mjx, mjy, mjz;
-            AG::sc(aj.x, &sj, &cj);
-            AG::sc(aj.y, &spj, &cpj);
+            AG::sc(thj, &sj, &cj);
+            AG::sc(phj, &spj, &cpj);
             const R njx = cpj * sj, njy = spj * sj, njz = cj;
             dipole<R, CT>(a_or_mu, k2e, njx, njy, njz, mjx, mjy, mjz);
             e0 += pair_term<R>(hb * (Nxy0.x + njx), hb * (Nxy0.y + njy), hb * (ct0 + njz),
@@ -280,10 +313,13 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         if constexpr (RARE) e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lag) + dU * nbeta_log2e);
         else                e = __builtin_amdgcn_exp2f(dU * nbeta_log2e);
         ok = eps * st0 < st1 * e;
+        if constexpr (Q) ok = ok && inside;
       }
 
       // ---- commit (branch-free): angles, observables, counters
-      R2 a1; a1.x = ok ? th1 : th0; a1.y = ok ? ph1 : ph0;
+      Cell a1;
+      if constexpr (Q) a1 = ok ? cell1 : a0;
+      else { a1.x = ok ? th1 : th0; a1.y = ok ? ph1 : ph0; }
       ang[d.idx * lanes + lane] = a1;
       const R m = ok ? (R)1 : (R)0;
       const P mm = {m, m};
@@ -307,8 +343,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       nacc_seg += ok ? 1 : 0;
       if (more) {  // forward the accepted angles into the prefetched row if it is the same monomer
         const bool same = dn.idx == d.idx;
-        an.x = same ? a1.x : an.x;
-        an.y = same ? a1.y : an.y;
+        if constexpr (Q) an = same ? a1 : an;
+        else { an.x = same ? a1.x : an.x; an.y = same ? a1.y : an.y; }
       }
 
       // ---- record! x 8, mcmc_eap_chain.jl:327-328 (every step, accepted or not)
@@ -359,13 +395,20 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
           phistep_d /= A.adj_scale;
           thstep_d /= A.adj_scale;
         }
-        phistep = (R)(phistep_d / AG::unit); thstep = (R)(thstep_d / AG::unit);
+        phistep = (R)(phistep_d / ph_unit); thstep = (R)(thstep_d / th_unit);
       }
     }
   }
 
   // ---- spill
-  {
+  if constexpr (Q) {
+    uint16_t *gth = (uint16_t *)S.ang, *gph = (uint16_t *)S.ang + (int64_t)n * C;
+    for (int i = 0; i < n; ++i) {
+      const uint32_t v = ang[i * lanes + lane];
+      gth[(int64_t)i * C + c] = (uint16_t)(v & 0xFFFFu);
+      gph[(int64_t)i * C + c] = (uint16_t)(v >> 16);
+    }
+  } else {
     R *gth = (R *)S.ang, *gph = (R *)S.ang + (int64_t)n * C;
     for (int i = 0; i < n; ++i) {
       const R2 v = ang[i * lanes + lane];
@@ -373,7 +416,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       gph[(int64_t)i * C + c] = v.y;
     }
   }
-  S.rng[0 * C + c] = g.s0; S.rng[1 * C + c] = g.s1; S.rng[2 * C + c] = g.s2; S.rng[3 * C + c] = g.s3;
+  g.store(S.rng + c, C);
   S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
   S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
   S.nacc_total[c] += nacc_seg;
@@ -397,7 +440,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
 // poll + one agent-scope acquire (placement-independent; cdna_hip_programming.md Guideline 16).
 // Deadlock-free for any residency: a job's predecessor was handed out earlier, to a workgroup that is
 // running and that itself only ever waits on still earlier jobs.
-template <typename R, int CT, int EN, bool FX, bool RARE, int TRIG>
+template <typename R, typename G, int CT, int EN, bool FX, bool RARE, int TRIG, int ST>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
                                                    const CaseConst *__restrict__ cases,
                                                    SweepRare rare, int *__restrict__ queue) {
@@ -436,7 +479,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
     // lanes own disjoint LDS columns and never exchange data: idle lanes just skip the body
     if (len > 0 && lane < A.lanes && local < A.chains_per_case) {
       const CaseConst cc = cases[icase];
-      run_segment<R, CT, EN, FX, RARE, TRIG>(A, S, cc, rare, smem, lane,
+      run_segment<R, G, CT, EN, FX, RARE, TRIG, ST>(A, S, cc, rare, smem, lane,
                                              icase * A.chains_per_case + local, A.step0 + first, len);
     }
     if (A.nseg > 1) {
@@ -524,7 +567,7 @@ __global__ __launch_bounds__(64) void reduce_stage2(const double *__restrict__ p
 // metropolis_acc (inc/acceptance.jl:1-3).  One thread per chain.  The reference's acceptor keeps
 // the log-density it cached at the last acceptance, so after an adoption its comparisons are offset
 // by `lag` until the next accepted move -- reproduced here.
-template <typename R>
+template <typename R, typename G>
 __global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
                               int chain_type, int energy_type, int force_init) {
   int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -533,15 +576,15 @@ __global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restri
   const CaseConst cc = cases[c / A.chains_per_case];
   R *th = (R *)S.ang, *ph = (R *)S.ang + n * C;
   R *nth = (R *)S.ang_tmp, *nph = (R *)S.ang_tmp + n * C;
-  Xoshiro128pp g;
-  g.s0 = S.rng[0 * C + c]; g.s1 = S.rng[1 * C + c]; g.s2 = S.rng[2 * C + c]; g.s3 = S.rng[3 * C + c];
+  G g;
+  g.load(S.rng + c, C);
   for (int64_t i = 0; i < n; ++i) nph[i * C + c] = store_phi<R>(u01<double>(g.next()));
   for (int64_t i = 0; i < n; ++i) nth[i * C + c] = store_theta<R>(u01<double>(g.next()));
 
   double r[3] = {0, 0, 0}, p[3] = {0, 0, 0}, usum = 0, upair = 0, prod_new = 1.0, prod_old = 1.0;
   double pnx = 0, pny = 0, pnz = 0, pmx = 0, pmy = 0, pmz = 0;
   for (int64_t i = 0; i < n; ++i) {
-    double t = (double)nth[i * C + c] * ang_unit<R>(), f = (double)nph[i * C + c] * ang_unit<R>();
+    double t = load_theta<R>(nth[i * C + c]), f = load_phi<R>(nph[i * C + c]);
     double st = sin(t), ct = cos(t), sp = sin(f), cp = cos(f);
     double nx = cp * st, ny = sp * st, nz = ct, mx, my, mz;
     if (chain_type == PSTAT_DIELECTRIC)
@@ -552,7 +595,7 @@ __global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restri
     p[0] += mx; p[1] += my; p[2] += mz;
     usum += -0.5 * cc.E0 * mz;
     prod_new *= st;
-    prod_old *= sin((double)th[i * C + c] * ang_unit<R>());
+    prod_old *= sin(load_theta<R>(th[i * C + c]));
     if (energy_type == PSTAT_ISING && i > 0) {
       double h = -cc.b / 2;
       upair += pair_term<double>(h * (pnx + nx), h * (pny + ny), h * (pnz + nz), pmx, pmy, pmz, mx, my, mz);
@@ -575,14 +618,16 @@ __global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restri
     S.obs[OBS_P1 * C + c] = p[0]; S.obs[OBS_P2 * C + c] = p[1]; S.obs[OBS_P3 * C + c] = p[2];
     S.obs[OBS_U * C + c] = U_new; S.obs[OBS_USUM * C + c] = usum;
   }
-  S.rng[0 * C + c] = g.s0; S.rng[1 * C + c] = g.s1; S.rng[2 * C + c] = g.s2; S.rng[3 * C + c] = g.s3;
+  g.store(S.rng + c, C);
 }
 
 // ------------------------------------------------------------------------------------------ dispatch
 
+static int cell_bytes(int precision) { return precision == PSTAT_F64 ? 16 : (precision == PSTAT_Q16 ? 4 : 8); }
+
 int choose_lanes(int precision, int64_t n, int energy_type) {
   (void)energy_type;
-  const int64_t per_lane = n * (precision == PSTAT_F64 ? 16 : 8);
+  const int64_t per_lane = n * cell_bytes(precision);
   const int64_t budget = 160 * 1024;
   for (int lanes = 64; lanes >= 8; lanes >>= 1)
     if (per_lane * lanes <= budget) return lanes;
@@ -591,37 +636,40 @@ int choose_lanes(int precision, int64_t n, int energy_type) {
 
 using SweepFn = void (*)(SweepArgs, DevState, const CaseConst *, SweepRare, int *);
 
-template <typename R, int CT, int EN, bool FX, bool RARE>
-static SweepFn pick_trig(int trig) {
+template <typename R, typename G, int CT, int EN, bool FX, bool RARE>
+static SweepFn pick_state(const LaunchCfg &cfg) {
   if constexpr (sizeof(R) == 8) {
-    return sweep_kernel<R, CT, EN, FX, RARE, 0>;
+    return sweep_kernel<R, G, CT, EN, FX, RARE, 0, 0>;
   } else {
-    return trig == 0 ? sweep_kernel<R, CT, EN, FX, RARE, 0> : sweep_kernel<R, CT, EN, FX, RARE, 1>;
+    if (cfg.precision == PSTAT_Q16) return sweep_kernel<R, G, CT, EN, FX, RARE, 1, 1>;
+    return sweep_kernel<R, G, CT, EN, FX, RARE, 1, 0>;
   }
 }
-template <typename R, int CT, int EN>
+template <typename R, typename G, int CT, int EN>
 static SweepFn pick_flags(const LaunchCfg &cfg) {
   const bool rare = cfg.do_flips || cfg.lag || cfg.umbrella;
-  if (cfg.has_fx) return rare ? pick_trig<R, CT, EN, true, true>(cfg.trig_mode)
-                              : pick_trig<R, CT, EN, true, false>(cfg.trig_mode);
-  return rare ? pick_trig<R, CT, EN, false, true>(cfg.trig_mode)
-              : pick_trig<R, CT, EN, false, false>(cfg.trig_mode);
+  if (cfg.has_fx) return rare ? pick_state<R, G, CT, EN, true, true>(cfg) : pick_state<R, G, CT, EN, true, false>(cfg);
+  return rare ? pick_state<R, G, CT, EN, false, true>(cfg) : pick_state<R, G, CT, EN, false, false>(cfg);
 }
-template <typename R>
+template <typename R, typename G>
 static SweepFn pick_model(const LaunchCfg &cfg) {
   const bool ising = cfg.energy_type == PSTAT_ISING;
   if (cfg.chain_type == PSTAT_DIELECTRIC)
-    return ising ? pick_flags<R, PSTAT_DIELECTRIC, PSTAT_ISING>(cfg)
-                 : pick_flags<R, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING>(cfg);
-  return ising ? pick_flags<R, PSTAT_POLAR, PSTAT_ISING>(cfg)
-               : pick_flags<R, PSTAT_POLAR, PSTAT_NONINTERACTING>(cfg);
+    return ising ? pick_flags<R, G, PSTAT_DIELECTRIC, PSTAT_ISING>(cfg)
+                 : pick_flags<R, G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING>(cfg);
+  return ising ? pick_flags<R, G, PSTAT_POLAR, PSTAT_ISING>(cfg)
+               : pick_flags<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING>(cfg);
+}
+template <typename R>
+static SweepFn pick_rng(const LaunchCfg &cfg) {
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_model<R, Xoshiro128pp>(cfg) : pick_model<R, Mwc64x>(cfg);
 }
 static SweepFn pick_sweep(const LaunchCfg &cfg) {
-  return cfg.precision == PSTAT_F64 ? pick_model<double>(cfg) : pick_model<float>(cfg);
+  return cfg.precision == PSTAT_F64 ? pick_rng<double>(cfg) : pick_rng<float>(cfg);
 }
 
 static int sweep_lds_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
-  return (int)(a.n * a.lanes * (cfg.precision == PSTAT_F64 ? 16 : 8));
+  return (int)(a.n * a.lanes * cell_bytes(cfg.precision));
 }
 
 hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
@@ -635,7 +683,8 @@ hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_
   if (e != hipSuccess) return e;
   if (lds_bytes) *lds_bytes = lds;
   if (blocks_per_cu) *blocks_per_cu = nb;
-  if (name) *name = cfg.precision == PSTAT_F64 ? "sweep_kernel<double>" : "sweep_kernel<float>";
+  if (name) *name = cfg.precision == PSTAT_F64 ? "sweep_kernel<double>"
+                 : (cfg.precision == PSTAT_Q16 ? "sweep_kernel<float, q16 state>" : "sweep_kernel<float>");
   return hipSuccess;
 }
 
@@ -655,28 +704,48 @@ hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState
   return hipGetLastError();
 }
 
+template <typename G>
+static void launch_init_g(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s, const CaseConst *cases,
+                          double phi_step, double theta_step, unsigned grid, hipStream_t stream) {
+  if (cfg.precision == PSTAT_F64)
+    hipLaunchKernelGGL((init_kernel<double, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
+                       cfg.chain_type, cfg.energy_type, phi_step, theta_step);
+  else if (cfg.precision == PSTAT_Q16)
+    hipLaunchKernelGGL((init_kernel<uint16_t, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
+                       cfg.chain_type, cfg.energy_type, phi_step, theta_step);
+  else
+    hipLaunchKernelGGL((init_kernel<float, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
+                       cfg.chain_type, cfg.energy_type, phi_step, theta_step);
+}
+
 hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                        const CaseConst *cases, double phi_step, double theta_step,
                        hipStream_t stream) {
   const unsigned grid = (unsigned)((s.C + 255) / 256);
-  if (cfg.precision == PSTAT_F64)
-    hipLaunchKernelGGL(init_kernel<double>, dim3(grid), dim3(256), 0, stream, a, s, cases,
-                       cfg.chain_type, cfg.energy_type, phi_step, theta_step);
-  else
-    hipLaunchKernelGGL(init_kernel<float>, dim3(grid), dim3(256), 0, stream, a, s, cases,
-                       cfg.chain_type, cfg.energy_type, phi_step, theta_step);
+  if (cfg.rng == PSTAT_RNG_XOSHIRO128PP) launch_init_g<Xoshiro128pp>(cfg, a, s, cases, phi_step, theta_step, grid, stream);
+  else launch_init_g<Mwc64x>(cfg, a, s, cases, phi_step, theta_step, grid, stream);
   return hipGetLastError();
+}
+
+template <typename G>
+static void launch_reinit_g(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s, const CaseConst *cases,
+                            int force_init, unsigned grid, hipStream_t stream) {
+  if (cfg.precision == PSTAT_F64)
+    hipLaunchKernelGGL((reinit_kernel<double, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
+                       cfg.chain_type, cfg.energy_type, force_init);
+  else if (cfg.precision == PSTAT_Q16)
+    hipLaunchKernelGGL((reinit_kernel<uint16_t, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
+                       cfg.chain_type, cfg.energy_type, force_init);
+  else
+    hipLaunchKernelGGL((reinit_kernel<float, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
+                       cfg.chain_type, cfg.energy_type, force_init);
 }
 
 hipError_t launch_reinit(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                          const CaseConst *cases, int force_init, hipStream_t stream) {
   const unsigned grid = (unsigned)((s.C + 255) / 256);
-  if (cfg.precision == PSTAT_F64)
-    hipLaunchKernelGGL(reinit_kernel<double>, dim3(grid), dim3(256), 0, stream, a, s, cases,
-                       cfg.chain_type, cfg.energy_type, force_init);
-  else
-    hipLaunchKernelGGL(reinit_kernel<float>, dim3(grid), dim3(256), 0, stream, a, s, cases,
-                       cfg.chain_type, cfg.energy_type, force_init);
+  if (cfg.rng == PSTAT_RNG_XOSHIRO128PP) launch_reinit_g<Xoshiro128pp>(cfg, a, s, cases, force_init, grid, stream);
+  else launch_reinit_g<Mwc64x>(cfg, a, s, cases, force_init, grid, stream);
   return hipGetLastError();
 }
 

@@ -102,15 +102,42 @@ __device__ __forceinline__ R pair_term(R rx, R ry, R rz, R mix, R miy, R miz, R 
   return (mimj - 3 * mir * mjr) / ((R)(4.0 * 3.14159265358979323846) * r3);
 }
 
-// stored angle unit: radians for f64, turns for f32 (see Ang<> below)
-template <typename R> __host__ __device__ constexpr double ang_unit() {
-  return sizeof(R) == 4 ? 6.28318530717958647692 : 1.0;
+// Stored angle formats (the element type of DevState::ang):
+//   double   : radians                                   (PSTAT_F64)
+//   float    : turns, theta/2pi in [0,1/2], phi/2pi in [0,1)   (PSTAT_F32, see Ang<> below)
+//   uint16_t : index on a 2^16-point MIDPOINT lattice,   (PSTAT_Q16)
+//              theta_k = pi (k + 1/2) / 65536,  phi_j = 2 pi (j + 1/2) / 65536
+template <typename T> __device__ __forceinline__ T store_phi(double u) {   // phi ~ U(0, 2pi), u in [0,1)
+  if constexpr (sizeof(T) == 2) return (T)(uint32_t)(u * 65536.0);
+  else if constexpr (sizeof(T) == 4) return (T)u;
+  else return (T)(6.28318530717958647692 * u);
 }
-template <typename R> __device__ __forceinline__ R store_phi(double u) {   // phi ~ U(0, 2pi)
-  return sizeof(R) == 4 ? (R)u : (R)(6.28318530717958647692 * u);
+template <typename T> __device__ __forceinline__ T store_theta(double u) { // theta ~ U(0, pi)
+  if constexpr (sizeof(T) == 2) return (T)(uint32_t)(u * 65536.0);
+  else if constexpr (sizeof(T) == 4) return (T)(0.5 * u);
+  else return (T)(3.14159265358979323846 * u);
 }
-template <typename R> __device__ __forceinline__ R store_theta(double u) { // theta ~ U(0, pi)
-  return sizeof(R) == 4 ? (R)(0.5 * u) : (R)(3.14159265358979323846 * u);
+template <typename T> __host__ __device__ inline double load_phi(T raw) {     // -> radians
+  if constexpr (sizeof(T) == 2) return 6.28318530717958647692 * ((double)raw + 0.5) / 65536.0;
+  else if constexpr (sizeof(T) == 4) return 6.28318530717958647692 * (double)raw;
+  else return (double)raw;
+}
+template <typename T> __host__ __device__ inline double load_theta(T raw) {   // -> radians
+  if constexpr (sizeof(T) == 2) return 3.14159265358979323846 * ((double)raw + 0.5) / 65536.0;
+  else if constexpr (sizeof(T) == 4) return 6.28318530717958647692 * (double)raw;
+  else return (double)raw;
+}
+// lattice index -> turns, exactly, without the quarter-rate v_cvt_f32_u32: 0x4B000000 | m is the
+// float 2^23 + m
+__device__ __forceinline__ float q16_theta_turns(uint32_t k) {  // (2k+1) 2^-18
+  return __builtin_fmaf(__uint_as_float(0x4B000001u | (k << 1)), 0x1p-18f, -32.0f);
+}
+__device__ __forceinline__ float q16_phi_turns(uint32_t j) {    // (2j+1) 2^-17
+  return __builtin_fmaf(__uint_as_float(0x4B000001u | (j << 1)), 0x1p-17f, -64.0f);
+}
+// round-to-nearest integer of (step * s) via the 1.5*2^23 magic constant (one fma, one integer sub)
+__device__ __forceinline__ int q16_disp(float step, float s) {
+  return (int)__float_as_uint(__builtin_fmaf(step, s, 12582912.0f)) - 0x4B400000;
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));

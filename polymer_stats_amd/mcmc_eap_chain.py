@@ -77,7 +77,8 @@ def build_parser() -> argparse.ArgumentParser:
     a("--num-chains", dest="num-chains", type=int, default=4096, help="independent chains run at once on the GPU(s) and pooled")
     a("--seed", dest="seed", type=int, default=0, help="seed of the per-chain counter-seeded generators")
     a("--devices", dest="devices", type=str, default="0", help="comma-separated HIP device ordinals; chains are sharded over them")
-    a("--precision", dest="precision", type=str, default="f32", help="device arithmetic: f32 (f64 running sums) | f64")
+    a("--rng", dest="rng", type=str, default="mwc64x", help="per-chain generator: mwc64x | xoshiro128++")
+    a("--precision", dest="precision", type=str, default="f32", help="device arithmetic: f32 (f64 running sums) | f64 | q16 (lattice angles, f32 arithmetic)")
     return p
 
 
@@ -109,9 +110,12 @@ def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int)
           "Ising": _lib.ISING}.get(pargs["energy-type"])
     if et is None:
         raise ReferenceError_("energy-type is not understood.")
-    prec = {"f32": _lib.F32, "f64": _lib.F64}.get(pargs["precision"])
+    prec = {"f32": _lib.F32, "f64": _lib.F64, "q16": _lib.Q16}.get(pargs["precision"])
     if prec is None:
         raise ReferenceError_(f"precision '{pargs['precision']}' not understood")
+    rng = {"mwc64x": _lib.RNG_MWC64X, "xoshiro128++": _lib.RNG_XOSHIRO128PP}.get(pargs["rng"])
+    if rng is None:
+        raise ReferenceError_(f"rng '{pargs['rng']}' not understood")
     return _lib.default_params(
         E0=pargs["E0"], K1=pargs["K1"], K2=pargs["K2"], mu=pargs["mu"], kT=pargs["kT"],
         Fz=pargs["Fz"], Fx=pargs["Fx"], b=pargs["mlen"],
@@ -120,7 +124,7 @@ def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int)
         steps_per_adjust=pargs["steps-per-adjust"], n=pargs["num-monomers"], num_chains=num_chains,
         seed=pargs["seed"], chain_id0=chain_id0, chain_type=ct, energy_type=et,
         do_flips=1 if pargs["do-flips"] else 0, umbrella=1 if pargs["umbrella-sampling"] else 0,
-        precision=prec, device=device)
+        precision=prec, device=device, rng=rng)
 
 
 @dataclass

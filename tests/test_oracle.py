@@ -41,6 +41,31 @@ def test_xoshiro128pp_matches_published_algorithm(oracle):
     assert oracle.xoshiro_stream(seed, chain + 1, 4)[1] != got[:4]
 
 
+def test_mwc64x_matches_big_integer_reference(oracle):
+    """MWC64X recurrence, the Philox-selected base state and the 2^40-output skip-ahead per chain,
+    against exact Python integers (independent of the oracle's 128-bit C arithmetic)."""
+    A = 4294883355
+    M = A * (1 << 32) - 1
+    assert M == 0xFFFEB81AFFFFFFFF and pow(A, 1 << 40, M) == 0x82A211110E454078
+    for seed, chain in [(0, 0), (0x1234567890abcdef, 77), (20260501, 65535), (5, 2 ** 40 + 3)]:
+        ph = oracle.philox([0, 0, 0x5eed, 1], [seed & M32, seed >> 32])
+        base = 1 + (ph[0] | ph[1] << 32) % (M - 2)
+        st = base * pow(A, chain * (1 << 40), M) % M
+        x, c = st & M32, st >> 32
+        init, outs = oracle.mwc64x_stream(seed, chain, 500)
+        assert init == (x, c)
+        for got in outs:
+            assert got == x ^ c
+            t = A * x + c
+            x, c = t & M32, t >> 32
+    # skip-ahead == stepping: chain k+1 starts exactly 2^40 outputs after chain k
+    st = (123456789 << 32) | 987654321
+    assert oracle.lib().eap_mwc64x_skip(st, 1000) == st * pow(A, 1000, M) % M
+    (x0, c0), _ = oracle.mwc64x_stream(9, 4, 1)
+    (x1, c1), _ = oracle.mwc64x_stream(9, 5, 1)
+    assert oracle.lib().eap_mwc64x_skip((c0 << 32) | x0, 1 << 40) == (c1 << 32) | x1
+
+
 def test_uniform_contract(oracle):
     L = oracle.lib()
     assert L.eap_u01(0) == 0.0
@@ -99,12 +124,13 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("rng", [0, 1])
 @pytest.mark.parametrize("kw", CASES)
-def test_faithful_and_fast_agree(oracle, kw):
+def test_faithful_and_fast_agree(oracle, kw, rng):
     """Same stream -> same accept/reject sequence, same final angles, same generator state; running
     sums equal to rounding.  This is what licenses the O(1)-energy form the kernels use."""
     for inits, force in ((1, 0), (3, 1), (3, 0)):
-        P = oracle.make_params(num_steps=4000, num_inits=inits, force_init=force, seed=17, stepout=500, **kw)
+        P = oracle.make_params(num_steps=4000, num_inits=inits, force_init=force, seed=17, stepout=500, rng=rng, **kw)
         a = oracle.run(P, 3, "faithful", trace=True, rows=True)
         b = oracle.run(P, 3, "fast", trace=True, rows=True)
         assert np.array_equal(a.accepted, b.accepted)

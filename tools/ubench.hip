@@ -11,7 +11,7 @@
 constexpr int ITERS = 4096;
 constexpr int ACC = 8;
 
-enum Op { FMA32, MULLO, MULHI, SIN, EXP2, RCP, FMA64, ADD64, XORSHIFT, CVT, PKFMA, LDSB64 };
+enum Op { FMA32, MULLO, MULHI, SIN, EXP2, RCP, FMA64, ADD64, XORSHIFT, CVT, PKFMA, LDSB64, MAD64, ALIGNBIT, XOR32, ADDU32, XOSHIRO, MWC64X };
 
 template <int OP>
 __global__ __launch_bounds__(64) void rate_kernel(float *out, int nrows) {
@@ -38,6 +38,10 @@ __global__ __launch_bounds__(64) void rate_kernel(float *out, int nrows) {
         x = __builtin_elementwise_fma(x, (v2){1.0001f, 1.0002f}, (v2){0.5f, 0.25f});
         a[i] = x.x;
       }
+      if (OP == MAD64) { unsigned long long t = (unsigned long long)u[i] * 4294883355ull + (unsigned long long)(uint32_t)a[i]; u[i] = (uint32_t)t; a[i] = __uint_as_float((uint32_t)(t >> 32)); }
+      if (OP == ALIGNBIT) u[i] = __builtin_amdgcn_alignbit(u[i], u[i], 25 - i);
+      if (OP == XOR32) u[i] = u[i] ^ (0x9E3779B9u + it);
+      if (OP == ADDU32) u[i] = u[i] + (0x9E3779B9u ^ it);
       if (OP == LDSB64) {
         uint32_t row = __umulhi(u[i], (uint32_t)nrows);
         float2 v = lds[row * 64 + threadIdx.x];
@@ -68,6 +72,45 @@ int run(const char *name, int waves_per_cu, int nrows = 0) {
   double per_simd = ns_per_instr / ((waves_per_cu + 3) / 4);
   printf("%-10s waves/CU=%2d  %8.3f ms   %.3f ns per wave-instr per wave  (%.2f cyc @2.4GHz; per-SIMD issue interval %.2f cyc)\n",
          name, waves_per_cu, ms, ns_per_instr, ns_per_instr * 2.4, per_simd * 2.4);
+  CHECK(hipFree(out));
+  return 0;
+}
+
+template <int GEN>
+__global__ __launch_bounds__(64) void gen_kernel(uint32_t *out) {
+  // one generator per lane, 4 outputs per iteration (what one MC step consumes)
+  uint32_t s0 = threadIdx.x * 2654435761u + 1, s1 = s0 ^ 0x9E3779B9u, s2 = s0 * 3u + 7u, s3 = ~s0;
+  uint32_t x = s0, c = s1 & 0x7fffffffu;
+  uint32_t acc = 0;
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (GEN == 0) {  // xoshiro128++
+        uint32_t a = s0 + s3; uint32_t r = ((a << 7) | (a >> 25)) + s0; uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t; s3 = (s3 << 11) | (s3 >> 21);
+        acc += r >> 9;
+      } else {         // MWC64X: one 32x32+64 multiply-add and one xor per output
+        uint32_t r = x ^ c;
+        unsigned long long t = (unsigned long long)x * 4294883355ull + c;
+        x = (uint32_t)t; c = (uint32_t)(t >> 32);
+        acc += r >> 9;
+      }
+    }
+  }
+  if (acc == 0x12345u) out[0] = acc;
+}
+template <int GEN>
+int run_gen(const char *name, int waves_per_cu) {
+  uint32_t *out; CHECK(hipMalloc(&out, 4));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  int grid = 256 * waves_per_cu;
+  hipLaunchKernelGGL(gen_kernel<GEN>, dim3(grid), dim3(64), 0, 0, out);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(gen_kernel<GEN>, dim3(grid), dim3(64), 0, 0, out);
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+  printf("%-14s waves/CU=%2d  %8.3f ms  -> %.1f cycles @2.4GHz per 4 outputs (one MC step) per wave\n", name, waves_per_cu, ms, ms * 1e6 * 2.4 / ITERS);
   CHECK(hipFree(out));
   return 0;
 }
@@ -104,6 +147,8 @@ int main() {
     run<FMA64>("fma_f64", w); run<ADD64>("add_f64", w); run<XORSHIFT>("xor/shl/rot", w);
     run<CVT>("cvt+add", w); run<PKFMA>("pk_fma_f32", w);
   }
+  for (int w : {4, 8}) { run<MAD64>("mad_u64_u32", w); run<ALIGNBIT>("alignbit", w); run<XOR32>("xor_b32", w); run<ADDU32>("add_u32", w); }
+  for (int w : {4, 8}) { run_gen<0>("xoshiro128++", w); run_gen<1>("mwc64x", w); }
   for (int w : {1, 2, 3}) run<LDSB64>("lds_b64_rand", w, 100);
   run<LDSB64>("lds_b64_rand", 8, 30);
   double *d; CHECK(hipMalloc(&d, 5 * 8)); CHECK(hipMemset(d, 0, 5 * 8));
