@@ -207,10 +207,6 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
 
   const bool inter = h->base.energy_type == PSTAT_INTERACTING;
   int lanes = inter ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
-  if (const char *le = getenv("PSTAT_LANES")) {  // experiment knob: fewer active lanes per wave
-    const int v = atoi(le);
-    if (!inter && v >= 1 && v <= lanes) lanes = v;
-  }
   if (lanes == 0) {
     delete h;
     return fail(PSTAT_ERR_UNSUPPORTED, "num-monomers = %lld does not fit the 160 KiB LDS of a CU",
@@ -246,6 +242,33 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   } while (0)
 
   CREATE_HIP(hipSetDevice(h->device));
+  if (!inter) {
+    // Chains per workgroup (active lanes of its single wave).  State lives in LDS, so a CU holds at
+    // most 160 KiB / (bytes per chain) chains; pick the lane count that minimises the makespan
+    // max(1, workgroups / resident slots) of one launch -- e.g. f32, n = 100: 51 lanes x 4
+    // workgroups per CU (204 chains, all four SIMDs) instead of 64 x 3 (192 chains, three SIMDs).
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, h->device));
+    int best = lanes;
+    double best_cost = 1e300;
+    const char *le = getenv("PSTAT_LANES");
+    for (int cand = lanes; cand >= 16; --cand) {
+      if (le && atoi(le) >= 1 && atoi(le) <= lanes && cand != atoi(le)) continue;
+      SweepArgs probe = h->args;
+      probe.lanes = cand;
+      int lds = 0, bpc = 0;
+      if (sweep_kernel_info(h->cfg, probe, &lds, &bpc, nullptr) != hipSuccess || bpc < 1) continue;
+      const double slots = (double)bpc * prop.multiProcessorCount;
+      const double wgs = (double)ncases * (double)((h->base.num_chains + cand - 1) / cand);
+      double cost = wgs / slots;
+      if (cost < 1.0) cost = 1.0;
+      cost *= 1.0 + 1e-4 * (64 - cand);   // ties: prefer fuller waves
+      if (cost < best_cost) { best_cost = cost; best = cand; }
+    }
+    lanes = best;
+    A.lanes = lanes;
+    A.blocks_per_case = (h->base.num_chains + lanes - 1) / lanes;
+  }
   if (stream) {
     h->stream = (hipStream_t)stream;
   } else {

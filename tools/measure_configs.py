@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Throughput of the BASELINE.json parity configurations (not the bench line): one launch each,
+timed with HIP events through torch on the stream the library launches on.
+    python tools/measure_configs.py [--quick]"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(ps, torch, name, cases, nsteps, repeats=3):
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        e = ps.Ensemble(cases, stream=stream.cuda_stream)
+        e.advance(min(nsteps, 2000))          # warm-up (also leaves the adaptation in its regime)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(repeats):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            e.advance(nsteps)
+            b.record(stream)
+            torch.cuda.synchronize()
+            times.append(a.elapsed_time(b))
+        info = e.launch_info()
+        s = e.summary(0)
+        chains = e.num_chains * e.ncases
+        ms = min(times)
+        out = dict(config=name, chains=chains, n=e.n, steps=nsteps, ms=round(ms, 3),
+                   updates_per_s=chains * nsteps / (ms * 1e-3), kernel=info.kernel.decode(),
+                   lds_bytes=info.lds_bytes, wg_per_cu=info.blocks_per_cu,
+                   r3=s.avg[2], p3=s.avg[9], U=s.avg[14], AR=s.acceptance_ratio)
+        e.close()
+    print(json.dumps(out), flush=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    import torch
+    import polymer_stats_amd as ps
+    q = 10 if args.quick else 1
+    P = ps.default_params
+    res = []
+    for prec, tag in ((ps.F32, "f32"), (ps.Q16, "q16"), (ps.F64, "f64")):
+        res.append(run(ps, torch, f"C1 n=20 E0=0 Fz=1 [{tag}]",
+                       P(n=20, E0=0.0, Fz=1.0, num_chains=65536, precision=prec, seed=1), 100000 // q))
+        res.append(run(ps, torch, f"C2 n=100 dielectric E0=1 K1=1 Fz=1 [{tag}]",
+                       P(n=100, E0=1.0, K1=1.0, Fz=1.0, num_chains=65536, precision=prec, seed=2), 100000 // q))
+        res.append(run(ps, torch, f"C3 n=100 polar mu=1 E0=1 Fz=1 [{tag}]",
+                       P(n=100, E0=1.0, mu=1.0, Fz=1.0, chain_type=ps.POLAR, num_chains=65536, precision=prec, seed=3),
+                       100000 // q))
+        if prec != ps.Q16:
+            res.append(run(ps, torch, f"C4 n=64 interacting dielectric E0=1 Fz=0.5 [{tag}]",
+                           P(n=64, E0=1.0, K1=1.0, Fz=0.5, energy_type=ps.INTERACTING, num_chains=16384, precision=prec,
+                             seed=4), 20000 // q))
+        # C5: (E0, kT) phase grid of run/K1_E0-kT-phase.jl:21-24 (26 x 21 = 546 points), n = 200
+        grid = [P(n=200, E0=0.2 * i, kT=10 ** (-2 + 0.2 * j), K1=1.0, num_chains=128, precision=prec, seed=1000 + 21 * i + j,
+                  energy_type=et) for i in range(26) for j in range(21) for et in (ps.NONINTERACTING,)]
+        res.append(run(ps, torch, f"C5 n=200 (E0,kT) grid 546 points x 128 chains, non-interacting [{tag}]", grid, 50000 // q))
+        grid = [P(n=200, E0=0.2 * i, kT=10 ** (-2 + 0.2 * j), K1=1.0, num_chains=128, precision=prec, seed=1000 + 21 * i + j,
+                  energy_type=ps.ISING) for i in range(26) for j in range(21)]
+        res.append(run(ps, torch, f"C5 n=200 (E0,kT) grid 546 points x 128 chains, Ising [{tag}]", grid, 50000 // q))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
