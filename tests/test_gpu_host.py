@@ -1,0 +1,59 @@
+"""End-to-end drop-in test on the GPU: the Python twin of the reference's command line writes the two
+CSV files and the ten stdout lines in the reference's formats (mcmc_eap_chain.jl:256-259,329-348,
+386-395), and the numbers in them agree with the CPU oracle run under the same options."""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_outputs_match_reference_formats_and_oracle(tmp_path, oracle):
+    from polymer_stats_amd import mcmc_eap_chain as host
+    prefix = str(tmp_path / "run")
+    argv = ["-n", "20", "-e", "1.0", "-J", "1.0", "-F", "0.5", "-N", "6000", "-s", "1500", "-v", "0",
+            "--num-chains", "2048", "--seed", "3", "--prefix", prefix]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert host.main(argv) == 0
+    lines = buf.getvalue().strip().splitlines()
+    assert [l.split("=")[0].strip() for l in lines] == ["<r>", "<r/nb>", "<rj2>", "<r2>", "<p>", "<pj2>", "<p2>", "<U>", "<U2>", "AR"]
+    vals = {l.split("=")[0].strip(): np.array(eval(l.split("=")[1]), dtype=float) for l in lines}   # as aggregate_mcmc.jl:71 does
+    np.testing.assert_allclose(vals["<r/nb>"], vals["<r>"] / 20.0, rtol=1e-12)
+    assert vals["<r2>"] == pytest.approx(vals["<rj2>"].sum(), rel=1e-9)
+
+    traj = open(prefix + "_trajectory.csv").read().strip().splitlines()
+    roll = open(prefix + "_rolling.csv").read().strip().splitlines()
+    assert traj[0] == "step,r1,r2,r3,p1,p2,p3,U"
+    assert roll[0] == "step,r1,r2,r3,r1sq,r2sq,r3sq,rsq,p1,p2,p3,p1sq,p2sq,p3sq,psq,U,Usq"
+    assert len(traj) == 1 + 4 and len(roll) == 1 + 4
+    assert [r.split(",")[0] for r in roll[1:]] == ["1500.0", "3000.0", "4500.0", "6000.0"]   # Float64-formatted step
+    last = np.array([float(x) for x in roll[-1].split(",")])
+    np.testing.assert_allclose(last[1:4], vals["<r>"], rtol=1e-12)
+    np.testing.assert_allclose(last[15], vals["<U>"], rtol=1e-12)
+    assert all(len(r.split(",")) == 8 for r in traj[1:]) and all(len(r.split(",")) == 17 for r in roll[1:])
+
+    # same options through the oracle (faithful mode), pooled over independent chains
+    P = oracle.make_params(n=20, E0=1.0, K1=1.0, Fz=0.5, num_steps=6000, seed=3, stepout=1500)
+    sums, norm, nacc = oracle.run_many(P, 10 ** 6, 192, nthreads=8, mode="faithful")
+    m = sums / norm[:, None]
+    se = m.std(0, ddof=1) / np.sqrt(m.shape[0])
+    got = np.r_[vals["<r>"], vals["<rj2>"], vals["<r2>"], vals["<p>"], vals["<pj2>"], vals["<p2>"], vals["<U>"], vals["<U2>"]]
+    z = (got - m.mean(0)) / (se * 1.03 + 1e-12)      # GPU side: 2048 chains, its own error is ~0.3 of the oracle's
+    assert np.all(np.abs(z) < 4.5), z
+    assert abs(float(vals["AR"]) - nacc.mean() / 6000) < 0.01
+
+
+def test_cli_multi_init_and_umbrella_run(tmp_path):
+    from polymer_stats_amd import mcmc_eap_chain as host
+    prefix = str(tmp_path / "m")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        host.main(["-n", "12", "-e", "0.8", "-F", "0.3", "-N", "2000", "-M", "2", "-I", "-B", "-s", "1000", "-v", "0",
+                   "--num-chains", "256", "--prefix", prefix, "-T", "polar", "-m", "0.7", "-u", "Ising",
+                   "--rng", "xoshiro128++", "--precision", "f64"])
+    assert len(buf.getvalue().strip().splitlines()) == 10
+    roll = open(prefix + "_rolling.csv").read().strip().splitlines()
+    assert [r.split(",")[0] for r in roll[1:]] == ["1000.0", "2000.0", "1000.0", "2000.0"]   # step restarts per init
