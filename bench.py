@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 FZ_SWEEP = [round(0.05 * i, 2) for i in range(21)] + [1.5 + 0.5 * i for i in range(8)]  # run/noninteracting-compare-*.jl:21
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz = 7.86e13 lane-ops/s
-VALU_OPS_PER_UPDATE = 220      # ~100 flop + 7 transcendentals + ~110 int per update
+VALU_OPS_PER_UPDATE = 220      # SURVEY.md 8(d) estimate; replaced by the PMC-measured count when profiles/ has one
 
 
 def host_cores():
@@ -182,13 +182,16 @@ def main():
         mean_ms = sum(kernel_ms) / len(kernel_ms)
         bytes_per_update = {ps.F32: 16, ps.F64: 32, ps.Q16: 8}[prec]   # one state cell read + written
         achieved = bytes_per_update * upd_per_launch / (mean_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, valu_ops, valu_src = None, VALU_OPS_PER_UPDATE, "SURVEY.md 8(d) estimate"
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 key = f"{args.precision}_n{args.n}_c{args.chains}_s{args.mc_steps}"
                 traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+                if rec.get(key, {}).get("valu_instructions_per_update_per_lane"):
+                    valu_ops = rec[key]["valu_instructions_per_update_per_lane"]
+                    valu_src = "SQ_INSTS_VALU x 64 / updates, profiles/pmc_traffic.json"
             except Exception:
                 traffic = None
         upd_rate_kernel = upd_per_launch / (mean_ms * 1e-3)
@@ -213,10 +216,10 @@ def main():
                          "kernel_ms": mean_ms,
                          "note": "algorithmic bytes = %d B/update x %d updates per launch; the kernel keeps state in "
                                  "LDS/registers, so HBM is not what bounds it -- see 'valu'" % (bytes_per_update, upd_per_launch)},
-            "valu": {"bound": "valu-issue", "achieved": upd_rate_kernel * VALU_OPS_PER_UPDATE / 1e12,
+            "valu": {"bound": "valu-issue", "achieved": upd_rate_kernel * valu_ops / 1e12,
                      "peak": VALU_LANE_OPS_PEAK / 1e12, "unit": "T lane-ops/s",
-                     "frac": upd_rate_kernel * VALU_OPS_PER_UPDATE / VALU_LANE_OPS_PEAK,
-                     "ops_per_update": VALU_OPS_PER_UPDATE},
+                     "frac": upd_rate_kernel * valu_ops / VALU_LANE_OPS_PEAK,
+                     "ops_per_update": valu_ops, "ops_source": valu_src},
             "check": {"Fz": FZ_SWEEP[(nstep_total - 1) % len(FZ_SWEEP)], "r3": last.avg[2], "r3_stderr": last.stderr[2],
                       "p3": last.avg[9], "U": last.avg[14], "AR": last.acceptance_ratio,
                       "chains_pooled": int(last.num_chains)},
