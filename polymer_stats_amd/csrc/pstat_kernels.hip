@@ -85,13 +85,14 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
 // ------------------------------------------------------------------------------------------ sweep
 
 struct Draw {  // raw words of one step's proposal, mcmc_eap_chain.jl:277-280,287
-  uint32_t idx, wphi, wth, weps, wflip;
+  uint32_t idx, cell, wphi, wth, weps, wflip;   // cell = idx * lanes + lane: the LDS slot of the monomer
 };
 
 template <bool RARE, typename G>
-__device__ __forceinline__ Draw draw_step(G &g, uint32_t n, bool flips) {
+__device__ __forceinline__ Draw draw_step(G &g, uint32_t n, bool flips, uint32_t lanes, uint32_t lane) {
   Draw d;
   d.idx = __umulhi(g.next(), n);
+  d.cell = d.idx * lanes + lane;
   d.wphi = g.next();
   d.wflip = 0;
   if constexpr (RARE) {
@@ -184,8 +185,10 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // step computes; if both steps hit the same monomer and the current one is accepted, the
   // prefetched row is replaced by the freshly accepted angles.
   using P = typename V2<R>::type;   // {old, new}
-  Draw d = draw_step<RARE>(g, (uint32_t)n, flips);
-  Cell a0 = ang[d.idx * lanes + lane];
+  Draw dA = draw_step<RARE>(g, (uint32_t)n, flips, (uint32_t)lanes, (uint32_t)lane), dB = dA;
+  Cell aA = ang[dA.cell], aB = aA;
+  R phistep3 = 3 * phistep, thstep3 = 3 * thstep;
+  (void)phistep3; (void)thstep3;
   int left = (int)remaining;        // steps still to run in this segment (<= 2^30)
   // running observables: (rx, ry) and (px, py) as pairs, the z components and U as scalars
   P Orxy = {O[0], O[1]}, Opxy = {O[3], O[4]};
@@ -200,16 +203,17 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     R a1rz = 0, a1pz = 0, a1U = 0, a2rz = 0, a2pz = 0, a2U = 0;
     R accw = 0;
 
-    for (int k = 0; k < chunk; ++k) {
-      const bool more = left - k > 1;  // wave-uniform (scalar compare)
-      Draw dn = d;
-      Cell an = a0;
+    // one Monte-Carlo step on (d, a0); fetches the next step's draws and LDS row into (dn, an)
+    auto one_step = [&](const Draw &d, const Cell &a0, Draw &dn, Cell &an, const bool more)
+        __attribute__((always_inline)) {
       if (more) {
-        dn = draw_step<RARE>(g, (uint32_t)n, flips);
-        an = ang[dn.idx * lanes + lane];
+        dn = draw_step<RARE>(g, (uint32_t)n, flips, (uint32_t)lanes, (uint32_t)lane);
+        an = ang[dn.cell];
       }
       // ---- proposal, mcmc_eap_chain.jl:277-280, and trial angles, inc/eap_chain.jl:232-236
-      const R eps = u01<R>(d.weps);
+      R eps;                        // u in [0,1) (f64) or 1 + u (f32: the -1 is folded into the test)
+      if constexpr (sizeof(R) == 8) eps = u01<R>(d.weps);
+      else eps = bits12(d.weps);
       R th0, ph0, th1, ph1;
       bool inside = true;           // q16: the trial theta stayed on the lattice (else: clamped => rejected)
       uint32_t cell1 = 0;           // q16: packed trial state
@@ -240,8 +244,9 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
           ph1 = AG::wrap(ph0 + dphi);
           th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
         } else {
-          ph1 = AG::wrap(fma_r(phistep, sym11<R>(d.wphi), ph0));
-          th1 = fmin(AG::theta_max, fmax((R)0, fma_r(thstep, sym11<R>(d.wth), th0 + flip)));
+          // angle + step * (f - 3) with f in [2,4): the -3*step rides on the base angle
+          ph1 = AG::wrap(fma_r(phistep, bits24(d.wphi), ph0 - phistep3));
+          th1 = fmin(AG::theta_max, fmax((R)0, fma_r(thstep, bits24(d.wth), (th0 + flip) - thstep3)));
         }
       }
       R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
@@ -312,7 +317,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         R e;
         if constexpr (RARE) e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lag) + dU * nbeta_log2e);
         else                e = __builtin_amdgcn_exp2f(dU * nbeta_log2e);
-        ok = eps * st0 < st1 * e;
+        ok = eps * st0 < fma_r(st1, e, st0);   // (1 + u) sin0 < sin1 e + sin0
         if constexpr (Q) ok = ok && inside;
       }
 
@@ -320,7 +325,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       Cell a1;
       if constexpr (Q) a1 = ok ? cell1 : a0;
       else { a1.x = ok ? th1 : th0; a1.y = ok ? ph1 : ph0; }
-      ang[d.idx * lanes + lane] = a1;
+      ang[d.cell] = a1;
       const R m = ok ? (R)1 : (R)0;
       const P mm = {m, m};
       if constexpr (sizeof(R) == 8) {  // the oracle's update order: r += b*dn, p += dm, U += dU
@@ -342,7 +347,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       }
       nacc_seg += ok ? 1 : 0;
       if (more) {  // forward the accepted angles into the prefetched row if it is the same monomer
-        const bool same = dn.idx == d.idx;
+        const bool same = dn.cell == d.cell;
         if constexpr (Q) an = same ? a1 : an;
         else { an.x = same ? a1.x : an.x; an.y = same ? a1.y : an.y; }
       }
@@ -362,8 +367,16 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         a1rz += Orz; a1pz += Opz; a1U += OU;
         a2rz = fma_r(Orz, Orz, a2rz); a2pz = fma_r(Opz, Opz, a2pz); a2U = fma_r(OU, OU, a2U);
       }
-      d = dn;
-      a0 = an;
+    };
+    // ping-pong between two (draw, row) register sets: no copies in the steady state
+    int k = 0;
+    for (; k + 1 < chunk; k += 2) {
+      one_step(dA, aA, dB, aB, true);
+      one_step(dB, aB, dA, aA, left - k > 2);
+    }
+    if (k < chunk) {
+      one_step(dA, aA, dB, aB, left - k > 1);
+      dA = dB; aA = aB;
     }
 
     R acc1[7] = {a1rxy.x, a1rxy.y, a1rz, a1pxy.x, a1pxy.y, a1pz, a1U};
@@ -396,6 +409,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
           thstep_d /= A.adj_scale;
         }
         phistep = (R)(phistep_d / ph_unit); thstep = (R)(thstep_d / th_unit);
+        phistep3 = 3 * phistep; thstep3 = 3 * thstep;
       }
     }
   }

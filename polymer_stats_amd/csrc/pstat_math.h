@@ -72,6 +72,10 @@ __device__ __forceinline__ R u01(uint32_t w) {
   if constexpr (sizeof(R) == 4) return __uint_as_float(0x3F800000u | (w >> 9)) - 1.0f;
   else return (R)(w >> 9) * (R)(1.0 / 8388608.0);
 }
+// the same two floats before the subtraction, built by one v_alignbit_b32: ({hi, w} >> 9) with
+// hi = 0x7F gives 0x3F800000 | (w >> 9) (a float in [1,2)), hi = 0x80 gives one in [2,4)
+__device__ __forceinline__ float bits12(uint32_t w) { return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, w, 9)); }
+__device__ __forceinline__ float bits24(uint32_t w) { return __uint_as_float(__builtin_amdgcn_alignbit(0x80u, w, 9)); }
 template <typename R>
 __device__ __forceinline__ R sym11(uint32_t w) {  // 2u - 1 in [-1,1)
   if constexpr (sizeof(R) == 4) return __uint_as_float(0x40000000u | (w >> 9)) - 3.0f;
