@@ -28,6 +28,10 @@
 #include "../../include/pstat.h"
 #include "pstat_math.h"
 
+#ifndef PSTAT_UNROLL
+#define PSTAT_UNROLL 8   // steps per basic block of the sweep loop (even)
+#endif
+
 namespace pstat {
 
 // ------------------------------------------------------------------------------------------ init
@@ -369,7 +373,18 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       }
     };
     // ping-pong between two (draw, row) register sets: no copies in the steady state
+    // ping-pong between two (draw, row) register sets -- no copies in the steady state -- and unroll
+    // PSTAT_UNROLL steps into one basic block: a lone wave issues independent instructions ~1.5x
+    // faster than dependent ones, and consecutive steps overlap (next step's generator, prefetch and
+    // old-state trig against the current step's tail)
     int k = 0;
+    for (; k + (PSTAT_UNROLL - 1) < chunk; k += PSTAT_UNROLL) {
+#pragma unroll
+      for (int u = 0; u < PSTAT_UNROLL; u += 2) {
+        one_step(dA, aA, dB, aB, true);
+        one_step(dB, aB, dA, aA, u + 2 < PSTAT_UNROLL || left - k > PSTAT_UNROLL);
+      }
+    }
     for (; k + 1 < chunk; k += 2) {
       one_step(dA, aA, dB, aB, true);
       one_step(dB, aB, dA, aA, left - k > 2);
