@@ -306,3 +306,50 @@ def test_errors_are_loud(ps):
     with pytest.raises(ps.PstatError) as ei:
         ps.Ensemble(ps.default_params(energy_type=ps.INTERACTING, n=100))   # > one wavefront
     assert ei.value.code == -4
+
+
+def test_full_size_config2_properties(ps, golden):
+    """BASELINE configs[1] at its full size (65 536 chains x 1e5 steps, n = 100, Fz = 1), checked
+    through size-independent properties: closed-form equilibrium values within the no-burn-in
+    transient (tau ~ 10 n = 1e3 steps => ~1 % low, ~2 % for the squares) plus 5 pooled standard errors; the sum rules
+    <r.r> = sum_j <r_j^2>, <p.p> = sum_j <p_j^2>; symmetry <r_x> = <r_y> = 0; variances positive;
+    every chain made exactly 1e5 attempts."""
+    nsteps, nch = 100000, 65536
+    pp = ps.default_params(num_chains=nch, precision=ps.F32, n=100, E0=1.0, K1=1.0, K2=0.0, Fz=1.0, seed=20260501)
+    with ps.Ensemble(pp) as e:
+        e.advance(nsteps)
+        s = e.summary()
+        st = e.chain_state(nch - 1)
+    avg, se = np.array(s.avg), np.array(s.stderr)
+    eq = golden["cfg2_n100_E0_1_K1_1_Fz1"]["avg"]
+    assert s.num_chains == nch and s.steps_per_chain == nsteps and s.attempted_updates == float(nch) * nsteps
+    assert st["steps_recorded"] == nsteps and 0 < st["nacc_total"] < nsteps
+    for k, name in enumerate(ps.OBS_NAMES):
+        want = eq[name]
+        tol = (0.03 if name.endswith("sq") else 0.015) * (abs(want) + 1.0) + 5 * se[k]
+        assert abs(avg[k] - want) < tol, (name, avg[k], want, se[k])
+    assert avg[6] == pytest.approx(avg[3] + avg[4] + avg[5], rel=1e-12)
+    assert avg[13] == pytest.approx(avg[10] + avg[11] + avg[12], rel=1e-12)
+    assert abs(avg[0]) < 5 * se[0] and abs(avg[1]) < 5 * se[1]
+    assert avg[5] > avg[2] ** 2 and avg[15] > avg[14] ** 2
+    assert 0.5 < s.acceptance_ratio < 0.7
+
+
+def test_edge_shapes(ps, oracle):
+    """Ragged and degenerate shapes: one chain, chain counts that do not fill a wave, n = 1 and 2,
+    one-step launches, zero-step launches, a field so strong that almost nothing is accepted."""
+    for n, nch, nsteps, kw in [(1, 1, 1, {}), (2, 1, 7, {}), (2, 65, 333, dict(do_flips=1)), (5, 130, 1, {}),
+                               (3, 7, 2501, dict(E0=30.0, K1=1.0, Fz=0.0, kT=0.05))]:
+        op, pp = both(nsteps, num_chains=nch, precision=ps.F64, n=n, seed=77, **({"E0": 1.0, "Fz": 0.5} | kw))
+        with ps.Ensemble(pp) as e:
+            e.advance(0)
+            e.advance(nsteps)
+            for c in sorted({0, nch - 1}):
+                o = oracle.run(op, chain_id=c, mode="fast", trace=True)
+                g = e.chain_state(c)
+                assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (n, nch, c)
+                assert g["nacc_total"] == o.nacc_total
+            s = e.summary()
+            assert s.num_chains == nch and np.all(np.isfinite(np.array(s.avg)))
+            if nch == 1:
+                assert np.all(np.array(s.stderr) == 0.0)     # one chain: no across-chain error
