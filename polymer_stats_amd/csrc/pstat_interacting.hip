@@ -7,17 +7,23 @@
 // scalar ALU beside the vector work.
 //   * trial positions: a move of monomer idx shifts x_idx by b/2 dn and every x_j, j > idx, by b dn
 //     (x_i = b (sum_{k<=i} n_k - n_i/2), inc/eap_chain.jl:49-51): three FMAs per lane, no scan;
-//   * the n(n-1)/2 pair terms: 32 lane rotations of (x, mu) with DPP `wave_ror:1` (no LDS traffic),
-//     lane i meets lane i-k at rotation k; rotation 32 is counted by the lower half only, so every
-//     pair is evaluated exactly once (2016 pairs at n = 64);
+//   * the n(n-1)/2 pair terms: the trial (x, mu) of every monomer is staged once per step in a
+//     128-entry LDS ring (entry m = monomer m mod 64), so "lane i meets lane i-k" is a read at a
+//     COMPILE-TIME offset from the lane's own slot: one ds_read_b128 + one ds_read_b64 per partner and
+//     no VALU work for addressing or data movement (a DPP rotation costs 6 quarter-rate moves per
+//     partner, measured in tools/ubench).  Rotations k = 1..31 meet every pair at circular distance
+//     k once; rotation 32 meets each of its pairs from both ends and is weighted 1/2: 2016 pairs at
+//     n = 64.  Lanes >= n carry zero dipoles at distinct far-away positions, so they contribute
+//     exactly 0 without a per-pair select;
 //   * one butterfly reduction gives the new pair energy to all lanes.
 // Full recomputation per step is the reference's own cost model (it recomputes U from scratch,
 // inc/eap_chain.jl:254); an exact incremental form would still touch ~n^2/6 pairs twice.
-// No LDS, no barrier, no atomics; HBM only at launch start/end.
+// One wave per workgroup: no barrier, no atomics; HBM only at launch start/end.
 #include "pstat_device.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 
 #include "../../include/pstat.h"
 #include "pstat_math.h"
@@ -77,17 +83,26 @@ __device__ __forceinline__ double lane_value<double>(double v, int src) {
 // the literal expression of inc/eap_chain.jl:200-207
 __device__ __forceinline__ float pair_fast(float rx, float ry, float rz, float mix, float miy, float miz,
                                            float mjx, float mjy, float mjz) {
-  const float r2 = rx * rx + ry * ry + rz * rz;
+  const float r2 = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
   const float ir = __builtin_amdgcn_rsqf(r2);
   const float ir2 = ir * ir;
-  const float mimj = mix * mjx + miy * mjy + miz * mjz;
-  const float mir = mix * rx + miy * ry + miz * rz;
-  const float mjr = mjx * rx + mjy * ry + mjz * rz;
-  return (mimj - 3.0f * mir * mjr * ir2) * (ir2 * ir) * 0.0795774715459476679f;  // 1/(4 pi)
+  const float mimj = __builtin_fmaf(miz, mjz, __builtin_fmaf(miy, mjy, mix * mjx));
+  const float mir = __builtin_fmaf(miz, rz, __builtin_fmaf(miy, ry, mix * rx));
+  const float mjr = __builtin_fmaf(mjz, rz, __builtin_fmaf(mjy, ry, mjx * rx));
+  const float num = __builtin_fmaf(-3.0f * ir2, mir * mjr, mimj);
+  return num * (ir2 * ir);   // x 1/(4 pi), applied once per sum
 }
 __device__ __forceinline__ double pair_fast(double rx, double ry, double rz, double mix, double miy,
                                             double miz, double mjx, double mjy, double mjz) {
-  return pair_term<double>(rx, ry, rz, mix, miy, miz, mjx, mjy, mjz);
+  // literal form of inc/eap_chain.jl:200-207 without its final 1/(4 pi)
+  const double r2 = rx * rx + ry * ry + rz * rz;
+  const double rmag = sqrt(r2);
+  const double hx = rx / rmag, hy = ry / rmag, hz = rz / rmag;
+  const double r3 = r2 * rmag;
+  const double mimj = mix * mjx + miy * mjy + miz * mjz;
+  const double mir = mix * hx + miy * hy + miz * hz;
+  const double mjr = mjx * hx + mjy * hy + mjz * hz;
+  return (mimj - 3 * mir * mjr) / r3;
 }
 
 template <typename R, typename G, int CT, int TRIG>
@@ -109,7 +124,7 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
   (void)kT; (void)nbeta_log2e;
 
   // which lane feeds me after one rotation step (robust against the rotate direction convention)
-  const int delta = (rotate1<int>(lane) - lane) & 63;
+  (void)rotate1<int>;
 
   // ---- fill: my monomer's angles; chain-level scalars are wave-uniform
   const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
@@ -147,19 +162,30 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
     usum = wave_allsum<R>(mhalfE0 * mz);
   };
   // sum over all pairs of the configuration (tx, tm) held one monomer per lane
+  using R4 = typename std::conditional<sizeof(R) == 4, float4, double4>::type;
+  using R2 = typename Vec2<R>::type;
+  __shared__ R4 ringA[128];   // (x, y, z, mu_x)
+  __shared__ R2 ringB[128];   // (mu_y, mu_z)
+  const R far = (R)1e6 * (R)(lane + 1);   // parking position of an unused lane
   auto pair_sum = [&](R tx, R ty, R tz, R tmx, R tmy, R tmz) -> R {
-    R qx = tx, qy = ty, qz = tz, qmx = tmx, qmy = tmy, qmz = tmz;
-    R e = 0;
-    int j = lane;
-#pragma unroll 4
+    R4 va; R2 vb;
+    va.x = real ? tx : far; va.y = real ? ty : (R)0; va.z = real ? tz : (R)0; va.w = tmx;
+    vb.x = tmy; vb.y = tmz;
+    __builtin_amdgcn_wave_barrier();            // previous step's reads are done (in-order LDS)
+    ringA[lane] = va; ringA[lane + 64] = va;
+    ringB[lane] = vb; ringB[lane + 64] = vb;
+    __builtin_amdgcn_wave_barrier();            // one wave: LDS executes its own ops in order
+    const R4 *pa = ringA + lane;
+    const R2 *pb = ringB + lane;
+    R e = 0, e32 = 0;
+#pragma unroll 8
     for (int k = 1; k <= 32; ++k) {
-      qx = rotate1<R>(qx); qy = rotate1<R>(qy); qz = rotate1<R>(qz);
-      qmx = rotate1<R>(qmx); qmy = rotate1<R>(qmy); qmz = rotate1<R>(qmz);
-      j = (j + delta) & 63;
-      const bool valid = real && j < n && (k < 32 || lane < 32);
-      const R t = pair_fast(tx - qx, ty - qy, tz - qz, tmx, tmy, tmz, qmx, qmy, qmz);
-      e += valid ? t : (R)0;
+      const R4 qa = pa[64 - k];                 // monomer (lane - k) mod 64
+      const R2 qb = pb[64 - k];
+      const R t = pair_fast(va.x - qa.x, va.y - qa.y, va.z - qa.z, tmx, tmy, tmz, qa.w, qb.x, qb.y);
+      if (k < 32) e += t; else e32 = t;
     }
+    e = (e + (R)0.5 * e32) * (R)0.0795774715459476679;   // 1/(4 pi)
     return wave_allsum<R>(e);
   };
   derive();

@@ -143,10 +143,12 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // ---- fill
   if constexpr (Q) {
     const uint16_t *gth = (const uint16_t *)S.ang, *gph = (const uint16_t *)S.ang + (int64_t)n * C;
+#pragma unroll 8
     for (int i = 0; i < n; ++i)
       ang[i * lanes + lane] = (uint32_t)gth[(int64_t)i * C + c] | ((uint32_t)gph[(int64_t)i * C + c] << 16);
   } else {
     const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
+#pragma unroll 8   // 16 independent loads in flight per batch
     for (int i = 0; i < n; ++i) {
       R2 v;
       v.x = gth[(int64_t)i * C + c];

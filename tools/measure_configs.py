@@ -10,7 +10,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+ONLY = ""
+
+
 def run(ps, torch, name, cases, nsteps, repeats=3):
+    if ONLY and ONLY not in name:
+        return None
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         e = ps.Ensemble(cases, stream=stream.cuda_stream)
@@ -40,13 +45,19 @@ def run(ps, torch, name, cases, nsteps, repeats=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="substring filter on the configuration name, e.g. 'C4'")
+    ap.add_argument("--precisions", default="f32,q16,f64")
     args = ap.parse_args()
     import torch
     import polymer_stats_amd as ps
+    global ONLY
+    ONLY = args.only
     q = 10 if args.quick else 1
     P = ps.default_params
     res = []
     for prec, tag in ((ps.F32, "f32"), (ps.Q16, "q16"), (ps.F64, "f64")):
+        if tag not in args.precisions.split(","):
+            continue
         res.append(run(ps, torch, f"C1 n=20 E0=0 Fz=1 [{tag}]",
                        P(n=20, E0=0.0, Fz=1.0, num_chains=65536, precision=prec, seed=1), 100000 // q))
         res.append(run(ps, torch, f"C2 n=100 dielectric E0=1 K1=1 Fz=1 [{tag}]",

@@ -11,7 +11,7 @@
 constexpr int ITERS = 4096;
 constexpr int ACC = 8;
 
-enum Op { FMA32, MULLO, MULHI, SIN, EXP2, RCP, FMA64, ADD64, XORSHIFT, CVT, PKFMA, LDSB64, MAD64, ALIGNBIT, XOR32, ADDU32, XOSHIRO, MWC64X };
+enum Op { FMA32, MULLO, MULHI, SIN, EXP2, RCP, FMA64, ADD64, XORSHIFT, CVT, PKFMA, LDSB64, MAD64, ALIGNBIT, XOR32, ADDU32, XOSHIRO, MWC64X, DPP_WAVE_ROR, DPP_ROW_ROR, BPERMUTE, DPP_WAVE_ROR_IND };
 
 template <int OP>
 __global__ __launch_bounds__(64) void rate_kernel(float *out, int nrows) {
@@ -42,6 +42,10 @@ __global__ __launch_bounds__(64) void rate_kernel(float *out, int nrows) {
       if (OP == ALIGNBIT) u[i] = __builtin_amdgcn_alignbit(u[i], u[i], 25 - i);
       if (OP == XOR32) u[i] = u[i] ^ (0x9E3779B9u + it);
       if (OP == ADDU32) u[i] = u[i] + (0x9E3779B9u ^ it);
+      if (OP == DPP_WAVE_ROR) u[i] = __builtin_amdgcn_update_dpp(0, (int)u[i], 0x13C, 0xF, 0xF, false);   // dependent chain per accumulator
+      if (OP == DPP_ROW_ROR) u[i] = __builtin_amdgcn_update_dpp(0, (int)u[i], 0x121, 0xF, 0xF, false);    // row_ror:1
+      if (OP == BPERMUTE) u[i] = __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x + 1) & 63) << 2), (int)u[i]);
+      if (OP == DPP_WAVE_ROR_IND) u[i] = u[i] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(threadIdx.x + it + i), 0x13C, 0xF, 0xF, false);
       if (OP == LDSB64) {
         uint32_t row = __umulhi(u[i], (uint32_t)nrows);
         float2 v = lds[row * 64 + threadIdx.x];
@@ -148,6 +152,7 @@ int main() {
     run<CVT>("cvt+add", w); run<PKFMA>("pk_fma_f32", w);
   }
   for (int w : {4, 8}) { run<MAD64>("mad_u64_u32", w); run<ALIGNBIT>("alignbit", w); run<XOR32>("xor_b32", w); run<ADDU32>("add_u32", w); }
+  for (int w : {4, 12, 16}) { run<DPP_WAVE_ROR>("dpp wave_ror", w); run<DPP_ROW_ROR>("dpp row_ror", w); run<BPERMUTE>("ds_bpermute", w); run<DPP_WAVE_ROR_IND>("wave_ror+add", w); }
   for (int w : {4, 8}) { run_gen<0>("xoshiro128++", w); run_gen<1>("mwc64x", w); }
   for (int w : {1, 2, 3}) run<LDSB64>("lds_b64_rand", w, 100);
   run<LDSB64>("lds_b64_rand", 8, 30);
