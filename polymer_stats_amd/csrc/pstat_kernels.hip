@@ -34,6 +34,7 @@
 
 namespace pstat {
 
+#ifndef PSTAT_PART   // (the per-precision sweep objects are built from this same file with -DPSTAT_PART=1|2|3)
 // ------------------------------------------------------------------------------------------ init
 
 // EAPChain(pargs), inc/eap_chain.jl:60-135: all phi draws, then all theta draws; then r, p, U.
@@ -85,6 +86,8 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
   S.uref[c] = usum;
   (void)omega;
 }
+
+#endif  // !PSTAT_PART
 
 // ------------------------------------------------------------------------------------------ sweep
 
@@ -523,6 +526,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
   }
 }
 
+#ifndef PSTAT_PART
 // ------------------------------------------------------------------------------------------ reduce
 
 constexpr int RED_BLOCKS = 256;
@@ -652,7 +656,54 @@ __global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restri
   g.store(S.rng + c, C);
 }
 
+#endif  // !PSTAT_PART
+
 // ------------------------------------------------------------------------------------------ dispatch
+
+using SweepFn = void (*)(SweepArgs, DevState, const CaseConst *, SweepRare, int *);
+
+#ifdef PSTAT_PART
+// One object per state format: 1 = f32 (turns), 2 = q16 (lattice, f32 arithmetic), 3 = f64.
+template <typename G, int CT, int EN, bool FX, bool RARE>
+static SweepFn pick_state() {
+#if PSTAT_PART == 3
+  return sweep_kernel<double, G, CT, EN, FX, RARE, 0, 0>;
+#elif PSTAT_PART == 2
+  return sweep_kernel<float, G, CT, EN, FX, RARE, 1, 1>;
+#else
+  return sweep_kernel<float, G, CT, EN, FX, RARE, 1, 0>;
+#endif
+}
+template <typename G, int CT, int EN>
+static SweepFn pick_flags(const LaunchCfg &cfg) {
+  const bool rare = cfg.do_flips || cfg.lag || cfg.umbrella;
+  if (cfg.has_fx) return rare ? pick_state<G, CT, EN, true, true>() : pick_state<G, CT, EN, true, false>();
+  return rare ? pick_state<G, CT, EN, false, true>() : pick_state<G, CT, EN, false, false>();
+}
+template <typename G>
+static SweepFn pick_model(const LaunchCfg &cfg) {
+  const bool ising = cfg.energy_type == PSTAT_ISING;
+  if (cfg.chain_type == PSTAT_DIELECTRIC)
+    return ising ? pick_flags<G, PSTAT_DIELECTRIC, PSTAT_ISING>(cfg)
+                 : pick_flags<G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING>(cfg);
+  return ising ? pick_flags<G, PSTAT_POLAR, PSTAT_ISING>(cfg)
+               : pick_flags<G, PSTAT_POLAR, PSTAT_NONINTERACTING>(cfg);
+}
+#if PSTAT_PART == 3
+SweepFn pick_sweep_f64(const LaunchCfg &cfg) {
+#elif PSTAT_PART == 2
+SweepFn pick_sweep_q16(const LaunchCfg &cfg) {
+#else
+SweepFn pick_sweep_f32(const LaunchCfg &cfg) {
+#endif
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_model<Xoshiro128pp>(cfg) : pick_model<Mwc64x>(cfg);
+}
+
+#else  // common object
+
+SweepFn pick_sweep_f32(const LaunchCfg &cfg);
+SweepFn pick_sweep_q16(const LaunchCfg &cfg);
+SweepFn pick_sweep_f64(const LaunchCfg &cfg);
 
 static int cell_bytes(int precision) { return precision == PSTAT_F64 ? 16 : (precision == PSTAT_Q16 ? 4 : 8); }
 
@@ -665,38 +716,9 @@ int choose_lanes(int precision, int64_t n, int energy_type) {
   return 0;
 }
 
-using SweepFn = void (*)(SweepArgs, DevState, const CaseConst *, SweepRare, int *);
-
-template <typename R, typename G, int CT, int EN, bool FX, bool RARE>
-static SweepFn pick_state(const LaunchCfg &cfg) {
-  if constexpr (sizeof(R) == 8) {
-    return sweep_kernel<R, G, CT, EN, FX, RARE, 0, 0>;
-  } else {
-    if (cfg.precision == PSTAT_Q16) return sweep_kernel<R, G, CT, EN, FX, RARE, 1, 1>;
-    return sweep_kernel<R, G, CT, EN, FX, RARE, 1, 0>;
-  }
-}
-template <typename R, typename G, int CT, int EN>
-static SweepFn pick_flags(const LaunchCfg &cfg) {
-  const bool rare = cfg.do_flips || cfg.lag || cfg.umbrella;
-  if (cfg.has_fx) return rare ? pick_state<R, G, CT, EN, true, true>(cfg) : pick_state<R, G, CT, EN, true, false>(cfg);
-  return rare ? pick_state<R, G, CT, EN, false, true>(cfg) : pick_state<R, G, CT, EN, false, false>(cfg);
-}
-template <typename R, typename G>
-static SweepFn pick_model(const LaunchCfg &cfg) {
-  const bool ising = cfg.energy_type == PSTAT_ISING;
-  if (cfg.chain_type == PSTAT_DIELECTRIC)
-    return ising ? pick_flags<R, G, PSTAT_DIELECTRIC, PSTAT_ISING>(cfg)
-                 : pick_flags<R, G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING>(cfg);
-  return ising ? pick_flags<R, G, PSTAT_POLAR, PSTAT_ISING>(cfg)
-               : pick_flags<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING>(cfg);
-}
-template <typename R>
-static SweepFn pick_rng(const LaunchCfg &cfg) {
-  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_model<R, Xoshiro128pp>(cfg) : pick_model<R, Mwc64x>(cfg);
-}
 static SweepFn pick_sweep(const LaunchCfg &cfg) {
-  return cfg.precision == PSTAT_F64 ? pick_rng<double>(cfg) : pick_rng<float>(cfg);
+  return cfg.precision == PSTAT_F64 ? pick_sweep_f64(cfg)
+       : (cfg.precision == PSTAT_Q16 ? pick_sweep_q16(cfg) : pick_sweep_f32(cfg));
 }
 
 static int sweep_lds_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
@@ -791,5 +813,7 @@ hipError_t launch_reduce(const DevState &s, int64_t c0, int64_t c1, int64_t step
   hipLaunchKernelGGL(reduce_stage2, dim3(2 * NQ), dim3(64), 0, stream, partial, c1 - c0, out);
   return hipGetLastError();
 }
+
+#endif  // PSTAT_PART
 
 }  // namespace pstat
