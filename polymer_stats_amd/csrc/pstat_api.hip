@@ -84,9 +84,9 @@ int validate(const pstat_params *c, int ncases) {
     return fail(PSTAT_ERR_INVALID_ARG, "chain-type is not understood.");       // eap_chain.jl:86
   if (b.energy_type < PSTAT_NONINTERACTING || b.energy_type > PSTAT_ISING)
     return fail(PSTAT_ERR_INVALID_ARG, "energy-type is not understood.");      // eap_chain.jl:104
-  if (b.energy_type == PSTAT_INTERACTING && b.n > 64)
-    return fail(PSTAT_ERR_UNSUPPORTED, "energy-type 'interacting' runs one chain per 64-lane wavefront: "
-                "num-monomers must be <= 64 (got %lld)", (long long)b.n);
+  if (b.energy_type == PSTAT_INTERACTING && b.n > 256)
+    return fail(PSTAT_ERR_UNSUPPORTED, "energy-type 'interacting' runs one chain per 64-lane wavefront with "
+                "up to 4 monomers per lane: num-monomers must be <= 256 (got %lld)", (long long)b.n);
   if (b.umbrella && b.energy_type == PSTAT_INTERACTING)
     return fail(PSTAT_ERR_UNSUPPORTED, "umbrella sampling is not implemented for energy-type 'interacting'");
   if (b.precision != PSTAT_F32 && b.precision != PSTAT_F64 && b.precision != PSTAT_Q16)
@@ -604,7 +604,7 @@ int pstat_launch_info_get(pstat_handle *h, pstat_launch_info *out) {
   std::memset(out, 0, sizeof *out);
   int lds = 0, bpc = 0;
   const char *name = "";
-  if (h->base.energy_type == PSTAT_INTERACTING) HIP_TRY(interacting_kernel_info(h->cfg, &bpc, &name));
+  if (h->base.energy_type == PSTAT_INTERACTING) HIP_TRY(interacting_kernel_info(h->cfg, h->base.n, &bpc, &name));
   else HIP_TRY(sweep_kernel_info(h->cfg, h->args, &lds, &bpc, &name));
   std::snprintf(out->kernel, sizeof out->kernel, "%s", name);
   out->lds_bytes = lds;

@@ -1,7 +1,8 @@
 // pstat_interacting.hip -- gfx950 kernel for --energy-type interacting (inc/energy.jl:11-16,
 // U_interaction inc/eap_chain.jl:196-211): every trial move needs the O(n^2) dipole-dipole sum.
 //
-// Mapping: ONE CHAIN PER WAVEFRONT, lane i owns monomer i (n <= 64).  Per lane in registers: the
+// Mapping: ONE CHAIN PER WAVEFRONT, lane l owns M = 1, 2 or 4 consecutive monomers (n <= 64 M = 256; the
+// reference's own interacting sweeps use n = 100 and 200, run/interacting_dielectric_study.jl:26).  Per lane in registers: the
 // angles, n-hat, dipole and position of its monomer.  Everything that is one-per-chain (generator,
 // proposal, r, p, U, running sums) is wave-uniform: the generator lives in SGPRs and runs on the
 // scalar ALU beside the vector work.
@@ -105,16 +106,23 @@ __device__ __forceinline__ double pair_fast(double rx, double ry, double rz, dou
   return (mimj - 3 * mir * mjr) / r3;
 }
 
-template <typename R, typename G, int CT, int TRIG>
+template <typename R>
+__device__ __forceinline__ R wave_excl_scan(R v, int lane) { return wave_incl_scan<R>(v, lane) - v; }
+
+// M consecutive monomers per lane: lane l owns monomers l*M .. l*M + M-1 (n <= 64 M).
+template <typename R, typename G, int CT, int TRIG, int M>
 __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S,
                                                          const CaseConst *__restrict__ cases,
                                                          int do_flips, int use_lag) {
   using AG = Ang<R, TRIG>;
+  using R4 = typename std::conditional<sizeof(R) == 4, float4, double4>::type;
+  using R2 = typename Vec2<R>::type;
+  __shared__ R4 ringA[128 * M];   // (x, y, z, mu_x) of monomer e mod 64M at entry e
+  __shared__ R2 ringB[128 * M];   // (mu_y, mu_z)
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   const int64_t C = S.C;
   const int n = (int)A.n;
-  const bool real = lane < n;
   const CaseConst cc = cases[c / A.chains_per_case];
   const R Fz = (R)cc.Fz, Fx = (R)cc.Fx, b = (R)cc.b, kT = (R)cc.kT;
   const R a_or_mu = (CT == PSTAT_DIELECTRIC) ? (R)((cc.K1 - cc.K2) * cc.E0) : (R)cc.mu;
@@ -123,13 +131,17 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
   const R nbeta_log2e = (R)(-1.4426950408889634 / cc.kT);
   (void)kT; (void)nbeta_log2e;
 
-  // which lane feeds me after one rotation step (robust against the rotate direction convention)
-  (void)rotate1<int>;
-
-  // ---- fill: my monomer's angles; chain-level scalars are wave-uniform
+  // ---- fill: my monomers' angles; chain-level scalars are wave-uniform
   const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
-  R th = real ? gth[(int64_t)lane * C + c] : (R)0;
-  R ph = real ? gph[(int64_t)lane * C + c] : (R)0;
+  R th[M], ph[M];
+  bool real[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const int i = lane * M + j;
+    real[j] = i < n;
+    th[j] = real[j] ? gth[(int64_t)i * C + c] : (R)0;
+    ph[j] = real[j] ? gph[(int64_t)i * C + c] : (R)0;
+  }
   G g;   // wave-uniform: one stream per chain, kept in SGPRs
   {
     uint32_t w[4];
@@ -145,49 +157,86 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
 #pragma unroll
   for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
 
-  // ---- derive my monomer and the chain totals (inc/eap_chain.jl:109-134)
-  R st, ct, sp, cp, nx, ny, nz, mx, my, mz, xx, xy, xz;
+  // ---- derive my monomers and the chain totals (inc/eap_chain.jl:109-134)
+  R st[M], nx[M], ny[M], nz[M], mx[M], my[M], mz[M], xx[M], xy[M], xz[M];
   R rx, ry, rz, px, py, pz, usum, upair, U;
   auto derive = [&]() {
-    AG::sc(th, &st, &ct);
-    AG::sc(ph, &sp, &cp);
-    nx = real ? cp * st : (R)0; ny = real ? sp * st : (R)0; nz = real ? ct : (R)0;
-    dipole<R, CT>(a_or_mu, k2e, nx, ny, nz, mx, my, mz);
-    if (!real) { mx = 0; my = 0; mz = 0; }
-    xx = b * (wave_incl_scan<R>(nx, lane) - (R)0.5 * nx);
-    xy = b * (wave_incl_scan<R>(ny, lane) - (R)0.5 * ny);
-    xz = b * (wave_incl_scan<R>(nz, lane) - (R)0.5 * nz);
-    rx = b * wave_allsum<R>(nx); ry = b * wave_allsum<R>(ny); rz = b * wave_allsum<R>(nz);
-    px = wave_allsum<R>(mx); py = wave_allsum<R>(my); pz = wave_allsum<R>(mz);
-    usum = wave_allsum<R>(mhalfE0 * mz);
+    R tnx = 0, tny = 0, tnz = 0, tmx = 0, tmy = 0, tmz = 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      R ct, sp, cp;
+      AG::sc(th[j], &st[j], &ct);
+      AG::sc(ph[j], &sp, &cp);
+      nx[j] = real[j] ? cp * st[j] : (R)0; ny[j] = real[j] ? sp * st[j] : (R)0; nz[j] = real[j] ? ct : (R)0;
+      dipole<R, CT>(a_or_mu, k2e, nx[j], ny[j], nz[j], mx[j], my[j], mz[j]);
+      if (!real[j]) { mx[j] = 0; my[j] = 0; mz[j] = 0; }
+      tnx += nx[j]; tny += ny[j]; tnz += nz[j];
+      tmx += mx[j]; tmy += my[j]; tmz += mz[j];
+    }
+    // x_i = b (sum_{k<=i} n_k - n_i / 2): lane-exclusive prefix + running sum inside the lane
+    R cx = wave_excl_scan<R>(tnx, lane), cy = wave_excl_scan<R>(tny, lane), cz = wave_excl_scan<R>(tnz, lane);
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      cx += nx[j]; cy += ny[j]; cz += nz[j];
+      xx[j] = b * (cx - (R)0.5 * nx[j]); xy[j] = b * (cy - (R)0.5 * ny[j]); xz[j] = b * (cz - (R)0.5 * nz[j]);
+    }
+    rx = b * wave_allsum<R>(tnx); ry = b * wave_allsum<R>(tny); rz = b * wave_allsum<R>(tnz);
+    px = wave_allsum<R>(tmx); py = wave_allsum<R>(tmy); pz = wave_allsum<R>(tmz);
+    usum = wave_allsum<R>(mhalfE0 * tmz);
   };
-  // sum over all pairs of the configuration (tx, tm) held one monomer per lane
-  using R4 = typename std::conditional<sizeof(R) == 4, float4, double4>::type;
-  using R2 = typename Vec2<R>::type;
-  __shared__ R4 ringA[128];   // (x, y, z, mu_x)
-  __shared__ R2 ringB[128];   // (mu_y, mu_z)
-  const R far = (R)1e6 * (R)(lane + 1);   // parking position of an unused lane
-  auto pair_sum = [&](R tx, R ty, R tz, R tmx, R tmy, R tmz) -> R {
-    R4 va; R2 vb;
-    va.x = real ? tx : far; va.y = real ? ty : (R)0; va.z = real ? tz : (R)0; va.w = tmx;
-    vb.x = tmy; vb.y = tmz;
+
+  // sum over all pairs of a configuration (tx, tm) held M monomers per lane
+  auto pair_sum = [&](const R (&tx)[M], const R (&ty)[M], const R (&tz)[M], const R (&tmx)[M],
+                      const R (&tmy)[M], const R (&tmz)[M]) -> R {
+    R4 va[M]; R2 vb[M];
     __builtin_amdgcn_wave_barrier();            // previous step's reads are done (in-order LDS)
-    ringA[lane] = va; ringA[lane + 64] = va;
-    ringB[lane] = vb; ringB[lane + 64] = vb;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const R far = (R)1e6 * (R)(lane * M + j + 1);   // parking position of an unused monomer
+      va[j].x = real[j] ? tx[j] : far; va[j].y = real[j] ? ty[j] : (R)0; va[j].z = real[j] ? tz[j] : (R)0;
+      va[j].w = tmx[j];
+      vb[j].x = tmy[j]; vb[j].y = tmz[j];
+      ringA[lane * M + j] = va[j]; ringA[(lane + 64) * M + j] = va[j];
+      ringB[lane * M + j] = vb[j]; ringB[(lane + 64) * M + j] = vb[j];
+    }
     __builtin_amdgcn_wave_barrier();            // one wave: LDS executes its own ops in order
-    const R4 *pa = ringA + lane;
-    const R2 *pb = ringB + lane;
+    const R4 *pa = ringA + lane * M;
+    const R2 *pb = ringB + lane * M;
     R e = 0, e32 = 0;
-#pragma unroll 8
+    // pairs inside the lane
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+#pragma unroll
+      for (int jp = j + 1; jp < M; ++jp)
+        e += pair_fast(va[j].x - va[jp].x, va[j].y - va[jp].y, va[j].z - va[jp].z, va[j].w, vb[j].x, vb[j].y,
+                       va[jp].w, vb[jp].x, vb[jp].y);
+    // pairs with the monomers of lane - k, k = 1..32 (k = 32 is met from both ends: weight 1/2)
+#pragma unroll 4
     for (int k = 1; k <= 32; ++k) {
-      const R4 qa = pa[64 - k];                 // monomer (lane - k) mod 64
-      const R2 qb = pb[64 - k];
-      const R t = pair_fast(va.x - qa.x, va.y - qa.y, va.z - qa.z, tmx, tmy, tmz, qa.w, qb.x, qb.y);
+      R t = 0;
+#pragma unroll
+      for (int jp = 0; jp < M; ++jp) {
+        const R4 qa = pa[(64 - k) * M + jp];
+        const R2 qb = pb[(64 - k) * M + jp];
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+          t += pair_fast(va[j].x - qa.x, va[j].y - qa.y, va[j].z - qa.z, va[j].w, vb[j].x, vb[j].y,
+                         qa.w, qb.x, qb.y);
+      }
       if (k < 32) e += t; else e32 = t;
     }
     e = (e + (R)0.5 * e32) * (R)0.0795774715459476679;   // 1/(4 pi)
     return wave_allsum<R>(e);
   };
+  // value of per-monomer array `a` at monomer idx (wave-uniform result)
+  auto at_idx = [&](const R (&a)[M], int owner, int slot) -> R {
+    R v = 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+      if (slot == j) v = lane_value<R>(a[j], owner);
+    return v;
+  };
+
   derive();
   upair = pair_sum(xx, xy, xz, mx, my, mz);
   U = usum + upair - (rx * Fx + rz * Fz);
@@ -208,15 +257,16 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
     for (int k = 0; k < (int)chunk; ++k) {
       // ---- proposal (wave-uniform), mcmc_eap_chain.jl:277-280
       const int idx = (int)__umulhi(g.next(), (uint32_t)n);
+      const int owner = idx / M, slot = idx % M;
       const R dphi = phistep * sym11<R>(g.next());
-      const R th0 = lane_value<R>(th, idx), ph0 = lane_value<R>(ph, idx);
+      const R th0 = at_idx(th, owner, slot), ph0 = at_idx(ph, owner, slot);
       R flip = 0;
       if (do_flips && (g.next() >> 31)) flip = AG::theta_max - 2 * th0;
       const R dth = flip + thstep * sym11<R>(g.next());
       const R eps = u01<R>(g.next());
-      const R st0 = lane_value<R>(st, idx);
-      const R n0x = lane_value<R>(nx, idx), n0y = lane_value<R>(ny, idx), n0z = lane_value<R>(nz, idx);
-      const R m0x = lane_value<R>(mx, idx), m0y = lane_value<R>(my, idx), m0z = lane_value<R>(mz, idx);
+      const R st0 = at_idx(st, owner, slot);
+      const R n0x = at_idx(nx, owner, slot), n0y = at_idx(ny, owner, slot), n0z = at_idx(nz, owner, slot);
+      const R m0x = at_idx(mx, owner, slot), m0y = at_idx(my, owner, slot), m0z = at_idx(mz, owner, slot);
 
       // ---- move!, inc/eap_chain.jl:232-253
       const R ph1 = AG::wrap(ph0 + dphi);
@@ -228,10 +278,16 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
       R m1x, m1y, m1z;
       dipole<R, CT>(a_or_mu, k2e, n1x, n1y, n1z, m1x, m1y, m1z);
       const R dnx = n1x - n0x, dny = n1y - n0y, dnz = n1z - n0z;
-      const bool mine = lane == idx;
-      const R w = lane > idx ? b : (mine ? (R)0.5 * b : (R)0);   // shift of x_lane in units of dn
-      const R tx = fma_r(w, dnx, xx), ty = fma_r(w, dny, xy), tz = fma_r(w, dnz, xz);
-      const R tmx = mine ? m1x : mx, tmy = mine ? m1y : my, tmz = mine ? m1z : mz;
+      R tx[M], ty[M], tz[M], tmx[M], tmy[M], tmz[M];
+      bool mine[M];
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const int i = lane * M + j;
+        mine[j] = i == idx;
+        const R w = i > idx ? b : (mine[j] ? (R)0.5 * b : (R)0);   // shift of x_i in units of dn
+        tx[j] = fma_r(w, dnx, xx[j]); ty[j] = fma_r(w, dny, xy[j]); tz[j] = fma_r(w, dnz, xz[j]);
+        tmx[j] = mine[j] ? m1x : mx[j]; tmy[j] = mine[j] ? m1y : my[j]; tmz[j] = mine[j] ? m1z : mz[j];
+      }
 
       // ---- energy, inc/energy.jl:13-16: sum(us) + U_interaction - F.r
       const R upair1 = pair_sum(tx, ty, tz, tmx, tmy, tmz);
@@ -251,11 +307,14 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
       }
       ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;   // one decision per chain
       if (ok) {
-        if (mine) {
-          th = th1; ph = ph1; st = st1;
-          nx = n1x; ny = n1y; nz = n1z; mx = m1x; my = m1y; mz = m1z;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          if (mine[j]) {
+            th[j] = th1; ph[j] = ph1; st[j] = st1;
+            nx[j] = n1x; ny[j] = n1y; nz[j] = n1z; mx[j] = m1x; my[j] = m1y; mz[j] = m1z;
+          }
+          xx[j] = tx[j]; xy[j] = ty[j]; xz[j] = tz[j];
         }
-        xx = tx; xy = ty; xz = tz;
         rx += drx; ry += dry; rz += drz;
         px += m1x - m0x; py += m1y - m0y; pz += m1z - m0z;
         usum += du; upair = upair1; U += dU;
@@ -309,10 +368,14 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
   }
 
   // ---- spill
-  if (real) {
+  {
     R *wth = (R *)S.ang, *wph = (R *)S.ang + (int64_t)n * C;
-    wth[(int64_t)lane * C + c] = th;
-    wph[(int64_t)lane * C + c] = ph;
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+      if (real[j]) {
+        wth[(int64_t)(lane * M + j) * C + c] = th[j];
+        wph[(int64_t)(lane * M + j) * C + c] = ph[j];
+      }
   }
   if (lane == 0) {
     g.store(S.rng + c, C);
@@ -329,26 +392,32 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
 
 using InterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int);
 
-template <typename G>
-static InterFn pick_interacting_g(const LaunchCfg &cfg) {
+template <typename G, int M>
+static InterFn pick_interacting_gm(const LaunchCfg &cfg) {
   const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
   if (cfg.precision == PSTAT_F64)
-    return diel ? interacting_kernel<double, G, PSTAT_DIELECTRIC, 0> : interacting_kernel<double, G, PSTAT_POLAR, 0>;
-  return diel ? interacting_kernel<float, G, PSTAT_DIELECTRIC, 1> : interacting_kernel<float, G, PSTAT_POLAR, 1>;
+    return diel ? interacting_kernel<double, G, PSTAT_DIELECTRIC, 0, M> : interacting_kernel<double, G, PSTAT_POLAR, 0, M>;
+  return diel ? interacting_kernel<float, G, PSTAT_DIELECTRIC, 1, M> : interacting_kernel<float, G, PSTAT_POLAR, 1, M>;
 }
-static InterFn pick_interacting(const LaunchCfg &cfg) {
-  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_interacting_g<Xoshiro128pp>(cfg) : pick_interacting_g<Mwc64x>(cfg);
+template <typename G>
+static InterFn pick_interacting_g(const LaunchCfg &cfg, int64_t n) {
+  if (n <= 64) return pick_interacting_gm<G, 1>(cfg);
+  if (n <= 128) return pick_interacting_gm<G, 2>(cfg);
+  return pick_interacting_gm<G, 4>(cfg);
+}
+static InterFn pick_interacting(const LaunchCfg &cfg, int64_t n) {
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_interacting_g<Xoshiro128pp>(cfg, n) : pick_interacting_g<Mwc64x>(cfg, n);
 }
 
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                               const CaseConst *cases, hipStream_t stream) {
-  InterFn fn = pick_interacting(cfg);
+  InterFn fn = pick_interacting(cfg, a.n);
   hipLaunchKernelGGL(fn, dim3((unsigned)s.C), dim3(64), 0, stream, a, s, cases, cfg.do_flips, cfg.lag);
   return hipGetLastError();
 }
 
-hipError_t interacting_kernel_info(const LaunchCfg &cfg, int *blocks_per_cu, const char **name) {
-  InterFn fn = pick_interacting(cfg);
+hipError_t interacting_kernel_info(const LaunchCfg &cfg, int64_t n, int *blocks_per_cu, const char **name) {
+  InterFn fn = pick_interacting(cfg, n);
   int nb = 0;
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fn, 64, 0);
   if (e != hipSuccess) return e;

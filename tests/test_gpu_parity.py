@@ -79,6 +79,14 @@ def test_f64_bit_parity_interacting_short_polar_flips(ps, oracle):
                 do_flips=1, seed=14, steps_per_adjust=250)
 
 
+@pytest.mark.parametrize("n", [100, 130, 200])
+def test_f64_bit_parity_interacting_long_chains(ps, oracle, n):
+    """n = 100 and 200 are what the reference's interacting sweeps run (run/interacting_*_study.jl):
+    2 or 4 monomers per lane."""
+    _bit_parity(ps, oracle, 400, 3, n=n, E0=1.0, K1=1.0, K2=0.1, Fz=0.5, Fx=0.1, energy_type=1, seed=23,
+                steps_per_adjust=100)
+
+
 def test_f32_interacting_statistical_parity(ps, oracle):
     """f32 interacting kernel vs CPU oracle (faithful = full O(n^2) recompute) under the same
     protocol: pooled means within 4.5 sigma."""
@@ -304,7 +312,7 @@ def test_errors_are_loud(ps):
     with pytest.raises(ps.PstatError):
         ps.Ensemble(ps.default_params(kT=0.0))
     with pytest.raises(ps.PstatError) as ei:
-        ps.Ensemble(ps.default_params(energy_type=ps.INTERACTING, n=100))   # > one wavefront
+        ps.Ensemble(ps.default_params(energy_type=ps.INTERACTING, n=300))   # > 4 monomers per lane
     assert ei.value.code == -4
 
 
