@@ -302,10 +302,10 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
             AG::sc(phj, &spj, &cpj);
             const R njx = cpj * sj, njy = spj * sj, njz = cj;
             dipole<R, CT>(a_or_mu, k2e, njx, njy, njz, mjx, mjy, mjz);
-            e0 += pair_term<R>(hb * (Nxy0.x + njx), hb * (Nxy0.y + njy), hb * (ct0 + njz),
-                               Mxy0.x, Mxy0.y, mz0, mjx, mjy, mjz);
-            e1 += pair_term<R>(hb * (Nxy1.x + njx), hb * (Nxy1.y + njy), hb * (ct1 + njz),
-                               Mxy1.x, Mxy1.y, mz1, mjx, mjy, mjz);
+            e0 += pair_term_fast(hb * (Nxy0.x + njx), hb * (Nxy0.y + njy), hb * (ct0 + njz),
+                                 Mxy0.x, Mxy0.y, mz0, mjx, mjy, mjz);
+            e1 += pair_term_fast(hb * (Nxy1.x + njx), hb * (Nxy1.y + njy), hb * (ct1 + njz),
+                                 Mxy1.x, Mxy1.y, mz1, mjx, mjy, mjz);
           }
         }
         dpair = e1 - e0;

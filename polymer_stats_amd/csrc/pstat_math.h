@@ -111,6 +111,23 @@ __device__ __forceinline__ R pair_term(R rx, R ry, R rz, R mix, R miy, R miz, R 
 //   float    : turns, theta/2pi in [0,1/2], phi/2pi in [0,1)   (PSTAT_F32, see Ang<> below)
 //   uint16_t : index on a 2^16-point MIDPOINT lattice,   (PSTAT_Q16)
 //              theta_k = pi (k + 1/2) / 65536,  phi_j = 2 pi (j + 1/2) / 65536
+// f32 form of pair_term for the hot loops: one v_rsq instead of sqrt + 4 divisions, explicit FMAs
+__device__ __forceinline__ float pair_term_fast(float rx, float ry, float rz, float mix, float miy, float miz,
+                                                float mjx, float mjy, float mjz) {
+  const float r2 = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
+  const float ir = __builtin_amdgcn_rsqf(r2);
+  const float ir2 = ir * ir;
+  const float mimj = __builtin_fmaf(miz, mjz, __builtin_fmaf(miy, mjy, mix * mjx));
+  const float mir = __builtin_fmaf(miz, rz, __builtin_fmaf(miy, ry, mix * rx));
+  const float mjr = __builtin_fmaf(mjz, rz, __builtin_fmaf(mjy, ry, mjx * rx));
+  const float num = __builtin_fmaf(-3.0f * ir2, mir * mjr, mimj);
+  return num * (ir2 * ir) * 0.0795774715459476679f;   // 1/(4 pi)
+}
+__device__ __forceinline__ double pair_term_fast(double rx, double ry, double rz, double mix, double miy,
+                                                 double miz, double mjx, double mjy, double mjz) {
+  return pair_term<double>(rx, ry, rz, mix, miy, miz, mjx, mjy, mjz);   // f64: the literal form
+}
+
 template <typename T> __device__ __forceinline__ T store_phi(double u) {   // phi ~ U(0, 2pi), u in [0,1)
   if constexpr (sizeof(T) == 2) return (T)(uint32_t)(u * 65536.0);
   else if constexpr (sizeof(T) == 4) return (T)u;
