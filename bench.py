@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f64", "q16"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend; gloo (via host memory) only to rehearse N>1 on a box with fewer GPUs")
     args = ap.parse_args()
 
     # Libraries (RCCL's version banner, HIP warnings) may write to stdout; the contract is ONE JSON
@@ -114,12 +116,29 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libpstat has no CPU path")
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    local_rank = local_rank % ndev          # (gloo rehearsal: ranks may share a GPU)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def all_reduce(tensor, op=None):
+        """Sum (or op) over ranks: RCCL on the device tensor, or gloo through host memory."""
+        kw = {} if op is None else {"op": op}
+        if args.backend == "nccl":
+            dist.all_reduce(tensor, **kw)
+        else:
+            host = tensor.cpu()
+            dist.all_reduce(host, **kw)
+            tensor.copy_(host)
 
     prec = {"f32": ps.F32, "f64": ps.F64, "q16": ps.Q16}[args.precision]
     stream = torch.cuda.Stream()
@@ -145,7 +164,7 @@ def main():
                 ev[1].record(stream)
             e.reduce_into(red.data_ptr())
             if use_dist:
-                dist.all_reduce(red)
+                all_reduce(red)
 
         for i in range(args.warmup):
             tw = time.perf_counter()
@@ -170,7 +189,7 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in events]
     last = ps.summary_from_reduction(red.cpu().tolist(), args.mc_steps)
