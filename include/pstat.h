@@ -136,6 +136,15 @@ int pstat_sync(pstat_handle *h);
  * (inc/acceptance.jl:1-3); the within-init step counter restarts at 1. */
 int pstat_reinit(pstat_handle *h, int32_t force_init);
 
+/* Burn-in support (the reference's clustering main, mcmc_clustering_eap_chain.jl:134-141,365-386,
+ * discards a burn-in run made on a temperature ladder; mcmc_eap_chain.jl itself records from step 1).
+ * pstat_reset_averages: zero the running sums, the acceptance totals and the recorded-step count,
+ * keep the chains, generators and adapted step sizes.  pstat_set_kT: change the temperature of case
+ * `icase` (all cases if < 0) for subsequent launches; the microstate is unaffected (U does not
+ * depend on kT). */
+int pstat_reset_averages(pstat_handle *h);
+int pstat_set_kT(pstat_handle *h, int32_t icase, double kT);
+
 /* Device-side reduction over the chains of case `icase` (or over all cases if icase < 0) into
  * `dev_out`, a DEVICE pointer to PSTAT_NRED doubles owned by the caller (e.g. a torch tensor that
  * is then all-reduced with RCCL).  Asynchronous on the handle's stream. */

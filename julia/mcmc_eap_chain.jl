@@ -82,6 +82,8 @@ s = ArgParseSettings();
   "--devices";             arg_type = String;  default = "0"
   "--precision";           arg_type = String;  default = "f32"
   "--rng";                 arg_type = String;  default = "mwc64x"
+  "--burn-in";             arg_type = Int;     default = 0
+  "--burn-schedule";       arg_type = String;  default = "[1]"
 end
 
 pargs = parse_args(s);
@@ -153,6 +155,18 @@ function mcmc(nsteps::Int, pargs)
   rollfile = open("$(pargs["prefix"])_rolling.csv", "w");
   println(rollfile, "step,r1,r2,r3,r1sq,r2sq,r3sq,rsq,p1,p2,p3,p1sq,p2sq,p3sq,psq,U,Usq");
 
+  if pargs["burn-in"] > 0   # temperature ladder whose records are discarded
+    for mult in eval(Meta.parse(pargs["burn-schedule"]))
+      for h in handles
+        check(ccall((:pstat_set_kT, LIBPSTAT), Cint, (Ptr{Cvoid}, Int32, Cdouble), h, -1, pargs["kT"] * mult))
+        check(ccall((:pstat_advance, LIBPSTAT), Cint, (Ptr{Cvoid}, Int64), h, pargs["burn-in"]))
+      end
+    end
+    for h in handles
+      check(ccall((:pstat_set_kT, LIBPSTAT), Cint, (Ptr{Cvoid}, Int32, Cdouble), h, -1, pargs["kT"]))
+      check(ccall((:pstat_reset_averages, LIBPSTAT), Cint, (Ptr{Cvoid},), h))
+    end
+  end
   start = time(); last_update = start; recorded = 0
   stepout = pargs["stepout"]
   for init = 1:pargs["num-inits"]

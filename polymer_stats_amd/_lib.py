@@ -21,7 +21,7 @@ OBS_NAMES = ["r1", "r2", "r3", "r1sq", "r2sq", "r3sq", "rsq",
 SYMBOLS = [
     "pstat_abi_version", "pstat_strerror", "pstat_last_error", "pstat_device_count",
     "pstat_default_params", "pstat_create", "pstat_destroy", "pstat_advance", "pstat_sync",
-    "pstat_reinit", "pstat_reduce_device", "pstat_reduce_host", "pstat_rolling", "pstat_microstate",
+    "pstat_reinit", "pstat_reset_averages", "pstat_set_kT", "pstat_reduce_device", "pstat_reduce_host", "pstat_rolling", "pstat_microstate",
     "pstat_summary_get", "pstat_summary_from_reduction", "pstat_chain_state",
     "pstat_checkpoint", "pstat_restore", "pstat_launch_info_get",
 ]
@@ -82,6 +82,8 @@ def load():
     L.pstat_advance.argtypes = [vp, i64]
     L.pstat_sync.argtypes = [vp]
     L.pstat_reinit.argtypes = [vp, i32]
+    L.pstat_reset_averages.argtypes = [vp]
+    L.pstat_set_kT.argtypes = [vp, i32, C.c_double]
     L.pstat_reduce_device.argtypes = [vp, i32, vp]
     L.pstat_reduce_host.argtypes = [vp, i32, dp]
     L.pstat_rolling.argtypes = [vp, i32, dp, dp]

@@ -420,6 +420,31 @@ int pstat_reinit(pstat_handle *h, int32_t force_init) {
   return PSTAT_OK;
 }
 
+int pstat_reset_averages(pstat_handle *h) {
+  if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const size_t C = (size_t)h->S.C;
+  HIP_TRY(hipMemsetAsync(h->S.sums, 0, NSUMS * C * sizeof(double), h->stream));
+  HIP_TRY(hipMemsetAsync(h->S.wnorm, 0, C * sizeof(double), h->stream));
+  HIP_TRY(hipMemsetAsync(h->S.nacc_total, 0, C * sizeof(int64_t), h->stream));
+  h->steps_recorded = 0;
+  return PSTAT_OK;
+}
+
+int pstat_set_kT(pstat_handle *h, int32_t icase, double kT) {
+  if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  if (!(kT > 0) || !std::isfinite(kT)) return fail(PSTAT_ERR_INVALID_ARG, "kT must be > 0");
+  if (icase >= h->ncases) return fail(PSTAT_ERR_INVALID_ARG, "case %d out of range", icase);
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));   // the host copy of the constants is re-uploaded
+  for (int i = 0; i < h->ncases; ++i)
+    if (icase < 0 || icase == i) h->cases[(size_t)i].kT = kT;
+  HIP_TRY(hipMemcpy(h->d_cases, h->cases.data(), sizeof(CaseConst) * (size_t)h->ncases, hipMemcpyHostToDevice));
+  return PSTAT_OK;
+}
+
 int pstat_reduce_device(pstat_handle *h, int32_t icase, double *dev_out) {
   if (!h || !dev_out) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
   if (icase >= h->ncases) return fail(PSTAT_ERR_INVALID_ARG, "case %d out of range", icase);

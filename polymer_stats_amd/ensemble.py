@@ -54,6 +54,13 @@ class Ensemble:
     def reinit(self, force_init: bool):
         check(self._L.pstat_reinit(self._h, 1 if force_init else 0))
 
+    def reset_averages(self):
+        """Discard what has been recorded so far (burn-in); chains, generators, step sizes stay."""
+        check(self._L.pstat_reset_averages(self._h))
+
+    def set_kT(self, kT: float, icase: int = -1):
+        check(self._L.pstat_set_kT(self._h, icase, float(kT)))
+
     # --- read-outs
     def reduce_into(self, dev_ptr: int, icase: int = -1):
         """Device-side reduction into a caller-owned device buffer of NRED doubles (async)."""

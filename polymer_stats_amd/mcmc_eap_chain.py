@@ -77,6 +77,10 @@ def build_parser() -> argparse.ArgumentParser:
     a("--num-chains", dest="num-chains", type=int, default=4096, help="independent chains run at once on the GPU(s) and pooled")
     a("--seed", dest="seed", type=int, default=0, help="seed of the per-chain counter-seeded generators")
     a("--devices", dest="devices", type=str, default="0", help="comma-separated HIP device ordinals; chains are sharded over them")
+    a("--burn-in", dest="burn-in", type=int, default=0,
+      help="steps discarded before averaging, per rung of --burn-schedule (0 = the reference's behaviour: record from step 1)")
+    a("--burn-schedule", dest="burn-schedule", type=str, default="[1]",
+      help="kT multipliers of the burn-in ladder, e.g. '[1000; 100; 10; 2; 1]' (mcmc_clustering_eap_chain.jl:138-141)")
     a("--rng", dest="rng", type=str, default="mwc64x", help="per-chain generator: mwc64x | xoshiro128++")
     a("--precision", dest="precision", type=str, default="f32", help="device arithmetic: f32 (f64 running sums) | f64 | q16 (lattice angles, f32 arithmetic)")
     return p
@@ -169,6 +173,18 @@ class _Pool:
         for e in self.parts:
             e.reinit(force)
 
+    def burn_in(self, nsteps, multipliers, kT):
+        """Run the temperature ladder without keeping anything it records."""
+        for mult in multipliers:
+            for e in self.parts:
+                e.set_kT(kT * mult)
+            for e in self.parts:
+                e.advance(nsteps)
+        for e in self.parts:
+            e.set_kT(kT)
+            e.reset_averages()
+        self.steps = 0
+
     def summary(self):
         red = np.zeros(_lib.NRED)
         for e in self.parts:
@@ -197,6 +213,9 @@ def mcmc(nsteps: int, pargs: dict):
                               "it has no device implementation")
     pool = _Pool(pargs)
     stepout = int(pargs["stepout"])
+    if pargs["burn-in"] > 0:
+        ladder = [float(x) for x in pargs["burn-schedule"].strip("[] ").replace(",", ";").split(";") if x.strip()]
+        pool.burn_in(int(pargs["burn-in"]), ladder or [1.0], pargs["kT"])
     try:
         with open(f"{pargs['prefix']}_trajectory.csv", "w") as outfile, \
                 open(f"{pargs['prefix']}_rolling.csv", "w") as rollfile:

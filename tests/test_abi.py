@@ -20,7 +20,7 @@ def ps():
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "pstat.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pstat_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(pstat_[A-Za-z_0-9]+)\s*\(", text)))
 
 
 def test_exports_every_declared_symbol(ps):

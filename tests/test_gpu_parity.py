@@ -361,3 +361,27 @@ def test_edge_shapes(ps, oracle):
             assert s.num_chains == nch and np.all(np.isfinite(np.array(s.avg)))
             if nch == 1:
                 assert np.all(np.array(s.stderr) == 0.0)     # one chain: no across-chain error
+
+
+@pytest.mark.parametrize("prec", [0, 2, 1])
+def test_equilibrium_after_burn_in_matches_closed_form_sharply(ps, golden, prec):
+    """With a burn-in the estimator has no transient, so the pooled averages must equal the
+    closed-form equilibrium values within their own (tiny) standard error: 65 536 chains x 5e4
+    recorded steps give ~7e-5 relative resolution on <r_z> -- a bias test of the f32 and lattice
+    arithmetic (and of the generator) three orders of magnitude sharper than the 1e-2-level tests."""
+    nch = 65536 if prec != 1 else 8192
+    pp = ps.default_params(num_chains=nch, precision=prec, n=100, E0=1.0, K1=1.0, K2=0.0, Fz=1.0, seed=424242)
+    with ps.Ensemble(pp) as e:
+        e.set_kT(3.0)
+        e.advance(10000)           # a short hot rung, then the target temperature
+        e.set_kT(1.0)
+        e.advance(30000)
+        e.reset_averages()
+        e.advance(50000)
+        s = e.summary()
+    avg, se = np.array(s.avg), np.array(s.stderr)
+    assert s.steps_per_chain == 50000
+    eq = golden["cfg2_n100_E0_1_K1_1_Fz1"]["avg"]
+    z = np.array([(avg[k] - eq[name]) / (se[k] + 1e-300) for k, name in enumerate(ps.OBS_NAMES)])
+    assert np.all(np.abs(z) < 5.0), dict(zip(ps.OBS_NAMES, np.round(z, 2)))
+    assert se[2] / eq["r3"] < (3e-4 if prec == 1 else 1e-4)    # the test really is that sharp
