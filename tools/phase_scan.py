@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4]: (E0, kT) phase-diagram scan at n = 200 (grid of run/K1_E0-kT-phase.jl:21-24:
+E0 in 0:0.2:5, kT in 10^(-2:0.2:2), K1 = 1, K2 = 0, b = 1, F = 0), all 546 grid points in ONE
+batched launch per GPU.  Chains of every grid point are sharded over the ranks by global chain id;
+the only exchange is one all-reduce(SUM) of the [points x 35] reduction tensor (RCCL when launched
+with torch.distributed.run, nothing at all for one GPU).
+
+    python tools/phase_scan.py --chains 128 --steps 50000 --burn-in 20000 --energy Ising --out scan.csv
+    python -m torch.distributed.run --nproc-per-node 8 tools/phase_scan.py ...
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=200)
+    ap.add_argument("--chains", type=int, default=128, help="chains per grid point per GPU")
+    ap.add_argument("--steps", type=int, default=50000)
+    ap.add_argument("--burn-in", type=int, default=20000)
+    ap.add_argument("--energy", choices=["noninteracting", "Ising"], default="Ising")
+    ap.add_argument("--precision", choices=["f32", "f64", "q16"], default="f32")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import polymer_stats_amd as ps
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    prec = {"f32": ps.F32, "f64": ps.F64, "q16": ps.Q16}[args.precision]
+    en = ps.ISING if args.energy == "Ising" else ps.NONINTERACTING
+    grid = [(0.2 * i, 10.0 ** (-2 + 0.2 * j)) for i in range(26) for j in range(21)]
+    cases = [ps.default_params(n=args.n, E0=E0, kT=kT, K1=1.0, K2=0.0, b=1.0, num_chains=args.chains,
+                               chain_id0=rank * args.chains, seed=20260501 + k, precision=prec,
+                               energy_type=en, device=local)
+             for k, (E0, kT) in enumerate(grid)]
+    stream = torch.cuda.Stream()
+    red = torch.zeros(len(grid), ps.NRED, dtype=torch.float64, device="cuda")
+    with torch.cuda.stream(stream):
+        e = ps.Ensemble(cases, stream=stream.cuda_stream)
+        t0 = time.perf_counter()
+        if args.burn_in > 0:
+            e.advance(args.burn_in)
+            e.reset_averages()
+        e.advance(args.steps)
+        for k in range(len(grid)):
+            e.reduce_into(red[k].data_ptr(), icase=k)
+        if world > 1:
+            dist.all_reduce(red)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    if rank == 0:
+        host = red.cpu().numpy()
+        rows = ["E0,kT,chains,r3,r3_stderr,rsq,p3,p3_stderr,psq,U,U_stderr,AR"]
+        for (E0, kT), v in zip(grid, host):
+            s = ps.summary_from_reduction(v, args.steps)
+            rows.append(",".join(f"{x:.10g}" for x in (E0, kT, s.num_chains, s.avg[2], s.stderr[2], s.avg[6], s.avg[9],
+                                                        s.stderr[9], s.avg[13], s.avg[14], s.stderr[14], s.acceptance_ratio)))
+        text = "\n".join(rows) + "\n"
+        if args.out:
+            open(args.out, "w").write(text)
+        else:
+            sys.stdout.write(text[:2000] + ("...\n" if len(text) > 2000 else ""))
+        upd = world * len(grid) * args.chains * (args.steps + args.burn_in)
+        print(f"# {len(grid)} grid points x {world * args.chains} chains, n={args.n}, {args.energy}, {args.precision}: "
+              f"{wall:.3f} s wall, {upd / wall:.3e} attempted updates/s", file=sys.stderr)
+    e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
