@@ -115,13 +115,6 @@ int validate(const pstat_params *c, int ncases) {
   return PSTAT_OK;
 }
 
-int trig_mode_from_env() {
-  const char *e = getenv("PSTAT_TRIG");
-  if (!e) return 1;   // 1 = hardware v_sin/v_cos on turns (default), 0 = OCML sincosf (A/B)
-  int v = atoi(e);
-  return v == 0 ? 0 : 1;
-}
-
 int set_device(pstat_handle *h) {
   HIP_TRY(hipSetDevice(h->device));
   return PSTAT_OK;
@@ -203,7 +196,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   bool any_fx = false;
   for (auto &c : h->cases) any_fx = any_fx || c.Fx != 0.0;
   h->cfg = {h->base.precision, h->base.chain_type, h->base.energy_type, h->base.do_flips ? 1 : 0,
-            h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, trig_mode_from_env(), 0, h->base.rng};
+            h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, 0, h->base.rng};
 
   const bool inter = h->base.energy_type == PSTAT_INTERACTING;
   int lanes = inter ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);

@@ -164,7 +164,7 @@ struct Mwc64x {
 
 // host-callable launchers implemented in pstat_kernels.hip; all asynchronous on `stream`
 struct LaunchCfg {
-  int precision, chain_type, energy_type, do_flips, umbrella, has_fx, trig_mode;
+  int precision, chain_type, energy_type, do_flips, umbrella, has_fx;
   int lag;  // a re-init has happened on this handle
   int rng;  // PSTAT_RNG_MWC64X | PSTAT_RNG_XOSHIRO128PP
 };

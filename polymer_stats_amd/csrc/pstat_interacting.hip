@@ -31,24 +31,6 @@
 
 namespace pstat {
 
-template <typename T>
-__device__ __forceinline__ T rotate1(T v);  // one lane step of the wave rotation used below
-template <>
-__device__ __forceinline__ float rotate1<float>(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C /* wave_ror:1 */, 0xF, 0xF, false));
-}
-template <>
-__device__ __forceinline__ int rotate1<int>(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xF, 0xF, false);
-}
-template <>
-__device__ __forceinline__ double rotate1<double>(double v) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x13C, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x13C, 0xF, 0xF, false);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
 template <typename R>
 __device__ __forceinline__ R wave_allsum(R v) {  // butterfly: every lane ends with the same bits
 #pragma unroll
@@ -110,11 +92,11 @@ template <typename R>
 __device__ __forceinline__ R wave_excl_scan(R v, int lane) { return wave_incl_scan<R>(v, lane) - v; }
 
 // M consecutive monomers per lane: lane l owns monomers l*M .. l*M + M-1 (n <= 64 M).
-template <typename R, typename G, int CT, int TRIG, int M>
+template <typename R, typename G, int CT, int M>
 __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S,
                                                          const CaseConst *__restrict__ cases,
                                                          int do_flips, int use_lag) {
-  using AG = Ang<R, TRIG>;
+  using AG = Ang<R>;
   using R4 = typename std::conditional<sizeof(R) == 4, float4, double4>::type;
   using R2 = typename Vec2<R>::type;
   __shared__ R4 ringA[128 * M];   // (x, y, z, mu_x) of monomer e mod 64M at entry e
@@ -396,8 +378,8 @@ template <typename G, int M>
 static InterFn pick_interacting_gm(const LaunchCfg &cfg) {
   const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
   if (cfg.precision == PSTAT_F64)
-    return diel ? interacting_kernel<double, G, PSTAT_DIELECTRIC, 0, M> : interacting_kernel<double, G, PSTAT_POLAR, 0, M>;
-  return diel ? interacting_kernel<float, G, PSTAT_DIELECTRIC, 1, M> : interacting_kernel<float, G, PSTAT_POLAR, 1, M>;
+    return diel ? interacting_kernel<double, G, PSTAT_DIELECTRIC, M> : interacting_kernel<double, G, PSTAT_POLAR, M>;
+  return diel ? interacting_kernel<float, G, PSTAT_DIELECTRIC, M> : interacting_kernel<float, G, PSTAT_POLAR, M>;
 }
 template <typename G>
 static InterFn pick_interacting_g(const LaunchCfg &cfg, int64_t n) {

@@ -117,12 +117,12 @@ struct SweepRare {  // wave-uniform switches of the rarely used options (RARE in
 };
 
 // One time-segment of one chain block: fill LDS/registers from HBM, run `nsteps` steps, spill.
-template <typename R, typename G, int CT, int EN, bool FX, bool RARE, int TRIG, int ST>
+template <typename R, typename G, int CT, int EN, bool FX, bool RARE, int ST>
 __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &S, const CaseConst &cc,
                                             const SweepRare rare, unsigned char *smem, const int lane,
                                             const int64_t c, int64_t step, int64_t remaining) {
   using R2 = typename Vec2<R>::type;
-  using AG = Ang<R, TRIG>;
+  using AG = Ang<R>;
   // ST = 0: the LDS cell is the (theta, phi) pair in R.  ST = 1 (PSTAT_Q16, R = float): the cell is
   // one 32-bit word, theta lattice index in the low half and phi index in the high half.
   constexpr bool Q = ST == 1;
@@ -474,7 +474,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
 // poll + one agent-scope acquire (placement-independent; cdna_hip_programming.md Guideline 16).
 // Deadlock-free for any residency: a job's predecessor was handed out earlier, to a workgroup that is
 // running and that itself only ever waits on still earlier jobs.
-template <typename R, typename G, int CT, int EN, bool FX, bool RARE, int TRIG, int ST>
+template <typename R, typename G, int CT, int EN, bool FX, bool RARE, int ST>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
                                                    const CaseConst *__restrict__ cases,
                                                    SweepRare rare, int *__restrict__ queue) {
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
     // lanes own disjoint LDS columns and never exchange data: idle lanes just skip the body
     if (len > 0 && lane < A.lanes && local < A.chains_per_case) {
       const CaseConst cc = cases[icase];
-      run_segment<R, G, CT, EN, FX, RARE, TRIG, ST>(A, S, cc, rare, smem, lane,
+      run_segment<R, G, CT, EN, FX, RARE, ST>(A, S, cc, rare, smem, lane,
                                              icase * A.chains_per_case + local, A.step0 + first, len);
     }
     if (A.nseg > 1) {
@@ -667,11 +667,11 @@ using SweepFn = void (*)(SweepArgs, DevState, const CaseConst *, SweepRare, int 
 template <typename G, int CT, int EN, bool FX, bool RARE>
 static SweepFn pick_state() {
 #if PSTAT_PART == 3
-  return sweep_kernel<double, G, CT, EN, FX, RARE, 0, 0>;
+  return sweep_kernel<double, G, CT, EN, FX, RARE, 0>;
 #elif PSTAT_PART == 2
-  return sweep_kernel<float, G, CT, EN, FX, RARE, 1, 1>;
+  return sweep_kernel<float, G, CT, EN, FX, RARE, 1>;
 #else
-  return sweep_kernel<float, G, CT, EN, FX, RARE, 1, 0>;
+  return sweep_kernel<float, G, CT, EN, FX, RARE, 0>;
 #endif
 }
 template <typename G, int CT, int EN>

@@ -15,49 +15,11 @@ template <typename R> struct Vec2;
 template <> struct Vec2<float> { using type = float2; };
 template <> struct Vec2<double> { using type = double2; };
 
-template <typename R> struct K;  // constants
-template <> struct K<float> {
-  static constexpr float pi = 3.14159274101257324f;  // (float)pi: > pi, so sin(pi) < 0 => clamp rejects
-  static constexpr float two_pi = 6.28318548202514648f;
-  static constexpr float half_pi = 1.57079637050628662f;
-};
+template <typename R> struct K;  // constants of the adaptation logic (f64, like the reference)
 template <> struct K<double> {
   static constexpr double pi = 3.14159265358979323846;
-  static constexpr double two_pi = 6.28318530717958647692;
   static constexpr double half_pi = 1.57079632679489661923;
 };
-
-// TRIG modes for the f32 path: 0 = OCML sincosf (<= 2 ulp), 1 = hardware v_sin/v_cos through the
-// fast-math intrinsics, 2 = own Cody-Waite + minimax polynomials (|x| <= 2 pi assumed).
-template <int TRIG>
-__device__ __forceinline__ void sincos_r(float x, float *s, float *c) {
-  if constexpr (TRIG == 0) {
-    sincosf(x, s, c);
-  } else if constexpr (TRIG == 1) {
-    *s = __sinf(x);
-    *c = __cosf(x);
-  } else {
-    float q = rintf(x * 0.636619746685028076f);           // x * 2/pi
-    float r = __builtin_fmaf(q, -1.57079625129699707f, x);  // pi/2 split hi
-    r = __builtin_fmaf(q, -7.54978941586159635e-08f, r);    // pi/2 split lo
-    int k = (int)q;
-    float r2 = r * r;
-    float ps = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = __builtin_fmaf(ps, r2, -1.6666654611e-1f);
-    float sn = __builtin_fmaf(ps * r2, r, r);
-    float pc = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = __builtin_fmaf(pc, r2, 4.166664568298827e-2f);
-    float cs = __builtin_fmaf(pc * r2, r2, __builtin_fmaf(r2, -0.5f, 1.0f));
-    float ss = (k & 1) ? cs : sn;
-    float cc = (k & 1) ? sn : cs;
-    *s = (k & 2) ? -ss : ss;
-    *c = ((k + 1) & 2) ? -cc : cc;
-  }
-}
-template <int TRIG>
-__device__ __forceinline__ void sincos_r(double x, double *s, double *c) {
-  sincos(x, s, c);
-}
 
 __device__ __forceinline__ float exp_r(float x) { return __expf(x); }
 __device__ __forceinline__ double exp_r(double x) { return exp(x); }
@@ -175,23 +137,19 @@ __device__ __forceinline__ v2d pfma(v2d a, v2d b, v2d c) { return a * b + c; }  
 //   f32: TURNS (theta/2pi in [0, 1/2], phi/2pi in [0, 1)).  gfx950's v_sin_f32/v_cos_f32 take turns
 //        and are accurate to 1.3e-7 absolute there (tools/ubench), phi wraps with one v_fract, and
 //        no range reduction or 1/2pi pre-scale is ever needed.
-template <typename R, int TRIG> struct Ang;
-template <int TRIG> struct Ang<double, TRIG> {
+template <typename R> struct Ang;
+template <> struct Ang<double> {
   static constexpr double theta_max = 3.14159265358979323846;
   static constexpr double unit = 1.0;  // radians per stored unit
   static __device__ __forceinline__ void sc(double x, double *s, double *c) { sincos(x, s, c); }
   static __device__ __forceinline__ double wrap(double x) { return x; }  // phi random-walks, eap_chain.jl:232
 };
-template <int TRIG> struct Ang<float, TRIG> {
+template <> struct Ang<float> {
   static constexpr float theta_max = 0.5f;
   static constexpr double unit = 6.28318530717958647692;
   static __device__ __forceinline__ void sc(float x, float *s, float *c) {
-    if constexpr (TRIG == 0) {
-      sincosf(x * 6.28318548202514648f, s, c);  // OCML reference path (A/B only)
-    } else {
-      *s = __builtin_amdgcn_sinf(x);
-      *c = __builtin_amdgcn_cosf(x);
-    }
+    *s = __builtin_amdgcn_sinf(x);   // v_sin_f32 / v_cos_f32 take turns
+    *c = __builtin_amdgcn_cosf(x);
   }
   static __device__ __forceinline__ float wrap(float x) { return __builtin_amdgcn_fractf(x); }
 };
