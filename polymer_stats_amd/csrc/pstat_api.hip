@@ -87,8 +87,6 @@ int validate(const pstat_params *c, int ncases) {
   if (b.energy_type == PSTAT_INTERACTING && b.n > 256)
     return fail(PSTAT_ERR_UNSUPPORTED, "energy-type 'interacting' runs one chain per 64-lane wavefront with "
                 "up to 4 monomers per lane: num-monomers must be <= 256 (got %lld)", (long long)b.n);
-  if (b.umbrella && b.energy_type == PSTAT_INTERACTING)
-    return fail(PSTAT_ERR_UNSUPPORTED, "umbrella sampling is not implemented for energy-type 'interacting'");
   if (b.precision != PSTAT_F32 && b.precision != PSTAT_F64 && b.precision != PSTAT_Q16)
     return fail(PSTAT_ERR_INVALID_ARG, "precision must be PSTAT_F32, PSTAT_F64 or PSTAT_Q16");
   if (b.precision == PSTAT_Q16 && b.energy_type == PSTAT_INTERACTING)
@@ -296,7 +294,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_HIP(launch_init(h->cfg, h->args, h->S, h->d_cases, h->base.phi_step, h->base.theta_step, h->stream));
   if (inter) {  // a zero-step launch derives r, p, U (with the pair energy) from the fresh angles
     h->args.nsteps = 0; h->args.step0 = 0;
-    CREATE_HIP(launch_interacting(h->cfg, h->args, h->S, h->d_cases, h->stream));
+    CREATE_HIP(launch_interacting(h->cfg, h->args, h->S, h->d_cases, 0, h->stream));
   }
   CREATE_HIP(hipStreamSynchronize(h->stream));  // h->cases must outlive the copy; also surfaces faults here
   if (!inter) {
@@ -348,7 +346,7 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
       const int64_t len = nsteps < max_launch ? nsteps : max_launch;
       h->args.nsteps = len;
       h->args.step0 = h->step_in_init;
-      HIP_TRY(launch_interacting(h->cfg, h->args, h->S, h->d_cases, h->stream));
+      HIP_TRY(launch_interacting(h->cfg, h->args, h->S, h->d_cases, 0, h->stream));
       h->step_in_init += len;
       h->steps_recorded += len;
       nsteps -= len;
@@ -402,11 +400,15 @@ int pstat_sync(pstat_handle *h) {
 
 int pstat_reinit(pstat_handle *h, int32_t force_init) {
   if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
-  if (h->base.energy_type == PSTAT_INTERACTING)
-    return fail(PSTAT_ERR_UNSUPPORTED, "re-initialisation (--num-inits > 1) is not implemented for "
-                "energy-type 'interacting'");
   int rc = set_device(h);
   if (rc) return rc;
+  if (h->base.energy_type == PSTAT_INTERACTING) {   // done inside the one-chain-per-wave kernel
+    h->args.nsteps = 0; h->args.step0 = 0;
+    HIP_TRY(launch_interacting(h->cfg, h->args, h->S, h->d_cases, force_init ? 2 : 1, h->stream));
+    h->step_in_init = 0;
+    h->cfg.lag = 1;
+    return PSTAT_OK;
+  }
   HIP_TRY(launch_reinit(h->cfg, h->args, h->S, h->d_cases, force_init, h->stream));
   h->step_in_init = 0;
   h->cfg.lag = 1;  // from now on the sweep tracks the acceptor's stale-cache offset

@@ -186,7 +186,7 @@ hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_
 int choose_lanes(int precision, int64_t n, int energy_type);
 // --energy-type interacting: one chain per wavefront (pstat_interacting.hip), n <= 256
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
-                              const CaseConst *cases, hipStream_t stream);
+                              const CaseConst *cases, int reinit_mode, hipStream_t stream);
 hipError_t interacting_kernel_info(const LaunchCfg &cfg, int64_t n, int *blocks_per_cu, const char **name);
 
 }  // namespace pstat

@@ -95,7 +95,8 @@ __device__ __forceinline__ R wave_excl_scan(R v, int lane) { return wave_incl_sc
 template <typename R, typename G, int CT, int M>
 __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S,
                                                          const CaseConst *__restrict__ cases,
-                                                         int do_flips, int use_lag) {
+                                                         int do_flips, int use_lag, int umb,
+                                                         int reinit_mode /* 0 | 1 metropolis | 2 forced */) {
   using AG = Ang<R>;
   using R4 = typename std::conditional<sizeof(R) == 4, float4, double4>::type;
   using R2 = typename Vec2<R>::type;
@@ -135,6 +136,10 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
   int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
   R lag = use_lag ? (R)S.lag[c] : (R)0;
+  // umbrella sampling (inc/average.jl:104-124), as in the sweep kernel: only w - w(first config) matters
+  const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
+  const R uref = umb ? (R)S.uref[c] : (R)0;
+  double wnorm = umb ? S.wnorm[c] : 0.0;
   double sums[NSUMS];
 #pragma unroll
   for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
@@ -223,6 +228,55 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
   upair = pair_sum(xx, xy, xz, mx, my, mz);
   U = usum + upair - (rx * Fx + rz * Fz);
 
+  if (reinit_mode) {
+    // mcmc_eap_chain.jl:352-361: draw a fresh configuration (all phi, then all theta, inc/eap_chain.jl:
+    // 61-62); adopt it if forced or by metropolis_acc (inc/acceptance.jl:1-3).  The acceptor's cached
+    // log-density is NOT refreshed by the reference, hence the `lag` offset (see reinit_kernel).
+    R oth[M], oph[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) { oth[j] = th[j]; oph[j] = ph[j]; }
+    const double U_old = (double)U, usum_old = (double)usum;
+    double lsin = 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) lsin += real[j] ? log((double)st[j]) : 0.0;
+    const double logp_old = wave_allsum<double>(lsin);
+    for (int i = 0; i < n; ++i) {
+      const R v = store_phi<R>(u01<double>(g.next()));
+#pragma unroll
+      for (int j = 0; j < M; ++j) if (lane * M + j == i) ph[j] = v;
+    }
+    for (int i = 0; i < n; ++i) {
+      const R v = store_theta<R>(u01<double>(g.next()));
+#pragma unroll
+      for (int j = 0; j < M; ++j) if (lane * M + j == i) th[j] = v;
+    }
+    derive();
+    upair = pair_sum(xx, xy, xz, mx, my, mz);
+    U = usum + upair - (rx * Fx + rz * Fz);
+    lsin = 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) lsin += real[j] ? log((double)st[j]) : 0.0;
+    const double logp_new = wave_allsum<double>(lsin);
+    bool adopt = reinit_mode == 2;
+    if (!adopt) {
+      const double eps = u01<double>(g.next());
+      adopt = eps <= exp(-((double)U - U_old) / cc.kT + (logp_new - logp_old));
+    }
+    adopt = __builtin_amdgcn_readfirstlane(adopt ? 1 : 0) != 0;
+    if (adopt) {
+      const double ws = (double)wscale;
+      const double lp_old = -U_old / cc.kT + logp_old + usum_old * ws;
+      const double lp_new = -(double)U / cc.kT + logp_new + (double)usum * ws;
+      lag = (R)((lp_old + (double)lag) - lp_new);
+    } else {
+#pragma unroll
+      for (int j = 0; j < M; ++j) { th[j] = oth[j]; ph[j] = oph[j]; }
+      derive();
+      upair = pair_sum(xx, xy, xz, mx, my, mz);
+      U = usum + upair - (rx * Fx + rz * Fz);
+    }
+  }
+
   int64_t step = A.step0;
   int64_t remaining = A.nsteps;
   const int64_t spa = A.steps_per_adjust;
@@ -232,7 +286,7 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
   while (remaining > 0) {
     int64_t chunk = remaining < FLUSH ? remaining : FLUSH;
     if (A.adaptive && to_adj < chunk) chunk = to_adj;
-    R acc1[7], acc2[7];
+    R acc1[7], acc2[7], accw = 0;
 #pragma unroll
     for (int q = 0; q < 7; ++q) { acc1[q] = 0; acc2[q] = 0; }
 
@@ -280,11 +334,12 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
 
       // ---- Metropolis, inc/acceptance.jl:18-39 (1/r^3 singularities give NaN => rejected)
       bool ok;
+      const R dw = du * wscale;   // change of the umbrella weight function (0 if off)
       if constexpr (sizeof(R) == 8) {
-        const R dlt = -dU / kT + log(st1 / st0) - lag;
+        const R dlt = -dU / kT + log(st1 / st0) + dw - lag;
         ok = (dlt >= 0) || (eps < exp(dlt));
       } else {
-        const R e = __builtin_amdgcn_exp2f((R)1.44269504f * (-lag) + dU * nbeta_log2e);
+        const R e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lag) + dU * nbeta_log2e);
         ok = eps * st0 < st1 * e;
       }
       ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;   // one decision per chain
@@ -303,11 +358,17 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
         lag = 0;
         ++nacc_seg;
       }
-      // ---- record! x 8, mcmc_eap_chain.jl:327-328
-      acc1[0] += rx; acc1[1] += ry; acc1[2] += rz; acc1[3] += px; acc1[4] += py; acc1[5] += pz; acc1[6] += U;
-      acc2[0] = fma_r(rx, rx, acc2[0]); acc2[1] = fma_r(ry, ry, acc2[1]); acc2[2] = fma_r(rz, rz, acc2[2]);
-      acc2[3] = fma_r(px, px, acc2[3]); acc2[4] = fma_r(py, py, acc2[4]); acc2[5] = fma_r(pz, pz, acc2[5]);
-      acc2[6] = fma_r(U, U, acc2[6]);
+      // ---- record! x 8, mcmc_eap_chain.jl:327-328 (UmbrellaAverager: value += v / e^w, inc/average.jl:63-67)
+      const R obs[7] = {rx, ry, rz, px, py, pz, U};
+      if (umb) {
+        const R wgt = exp_r(-(usum - uref) * wscale);
+        accw += wgt;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { acc1[q] = fma_r(wgt, obs[q], acc1[q]); acc2[q] = fma_r(wgt * obs[q], obs[q], acc2[q]); }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { acc1[q] += obs[q]; acc2[q] = fma_r(obs[q], obs[q], acc2[q]); }
+      }
     }
 
     sums[S_R1] += (double)acc1[0]; sums[S_R2] += (double)acc1[1]; sums[S_R3] += (double)acc1[2];
@@ -316,6 +377,7 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
     sums[S_R1SQ] += (double)acc2[0]; sums[S_R2SQ] += (double)acc2[1]; sums[S_R3SQ] += (double)acc2[2];
     sums[S_P1SQ] += (double)acc2[3]; sums[S_P2SQ] += (double)acc2[4]; sums[S_P3SQ] += (double)acc2[5];
     sums[S_USQ] += (double)acc2[6];
+    wnorm += (double)accw;
     step += chunk;
     remaining -= chunk;
     steps_seg += (int)chunk;
@@ -368,11 +430,12 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
     S.obs[OBS_P1 * C + c] = px; S.obs[OBS_P2 * C + c] = py; S.obs[OBS_P3 * C + c] = pz;
     S.obs[OBS_U * C + c] = U; S.obs[OBS_USUM * C + c] = usum;
     S.lag[c] = lag;
+    if (umb) S.wnorm[c] = wnorm;
     for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
   }
 }
 
-using InterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int);
+using InterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int, int, int);
 
 template <typename G, int M>
 static InterFn pick_interacting_gm(const LaunchCfg &cfg) {
@@ -392,9 +455,10 @@ static InterFn pick_interacting(const LaunchCfg &cfg, int64_t n) {
 }
 
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
-                              const CaseConst *cases, hipStream_t stream) {
+                              const CaseConst *cases, int reinit_mode, hipStream_t stream) {
   InterFn fn = pick_interacting(cfg, a.n);
-  hipLaunchKernelGGL(fn, dim3((unsigned)s.C), dim3(64), 0, stream, a, s, cases, cfg.do_flips, cfg.lag);
+  hipLaunchKernelGGL(fn, dim3((unsigned)s.C), dim3(64), 0, stream, a, s, cases, cfg.do_flips,
+                     (cfg.lag || reinit_mode) ? 1 : 0, cfg.umbrella, reinit_mode);
   return hipGetLastError();
 }
 

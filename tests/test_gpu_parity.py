@@ -87,6 +87,27 @@ def test_f64_bit_parity_interacting_long_chains(ps, oracle, n):
                 steps_per_adjust=100)
 
 
+def test_f64_interacting_umbrella_and_reinit(ps, oracle):
+    """The remaining options of the in-scope main on the interacting kernel: --umbrella-sampling and
+    --num-inits (forced and Metropolis re-initialisation, with the acceptor's stale cache)."""
+    for force, umb, n in ((1, 0, 20), (0, 0, 20), (0, 1, 70)):
+        nsteps, inits = 600, 3
+        op, pp = both(nsteps, num_chains=5, precision=ps.F64, num_inits=inits, force_init=force, umbrella=umb,
+                      n=n, E0=1.0, K1=1.0, K2=0.1, Fz=0.3, energy_type=1, seed=37, steps_per_adjust=200)
+        with ps.Ensemble(pp) as e:
+            for k in range(inits):
+                e.advance(nsteps)
+                if k + 1 < inits:
+                    e.reinit(bool(force))
+            for c in (0, 4):
+                o = oracle.run(op, chain_id=c, mode="fast", trace=True)
+                g = e.chain_state(c)
+                assert np.array_equal(g["theta"], o.final_theta), (force, umb, c)
+                assert np.array_equal(g["rng"], o.rng)
+                assert g["nacc_total"] == o.nacc_total
+                np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-8, atol=1e-8)
+
+
 def test_f32_interacting_statistical_parity(ps, oracle):
     """f32 interacting kernel vs CPU oracle (faithful = full O(n^2) recompute) under the same
     protocol: pooled means within 4.5 sigma."""
