@@ -31,7 +31,11 @@ class EapParams(C.Structure):
                 ("n", "num_steps", "num_inits", "steps_per_adjust", "stepout")] + \
                [("seed", C.c_uint64)] + \
                [(k, C.c_int32) for k in
-                ("chain_type", "energy_type", "do_flips", "force_init", "umbrella", "rng")]
+                ("chain_type", "energy_type", "do_flips", "force_init", "umbrella", "rng")] + \
+               [(k, C.c_double) for k in
+                ("bend_mod", "bend_angle", "cluster_prob", "x0_phi", "x0_theta", "dx0_phi", "dx0_theta")] + \
+               [("burn_sched", C.c_double * 8), ("burn_in", C.c_int64),
+                ("burn_nsched", C.c_int32), ("use_x0", C.c_int32)]
 
 
 class EapResult(C.Structure):
@@ -39,7 +43,7 @@ class EapResult(C.Structure):
                 ("nacc_total", C.c_int64), ("nsteps_total", C.c_int64),
                 ("phi_step", C.c_double), ("theta_step", C.c_double),
                 ("r", C.c_double * 3), ("p", C.c_double * 3), ("U", C.c_double),
-                ("rng", C.c_uint32 * 4)]
+                ("rng", C.c_uint32 * 4), ("extra_sum", C.c_double * 2)]
 
 
 class EapTrace(C.Structure):
@@ -76,7 +80,7 @@ def lib():
         L.eap_mwc64x_skip.restype = C.c_uint64
         L.eap_u01.argtypes = [C.c_uint32]
         L.eap_u01.restype = C.c_double
-        for f in (L.eap_run_faithful, L.eap_run_fast):
+        for f in (L.eap_run_faithful, L.eap_run_fast, L.eap_run_cluster):
             f.argtypes = [C.POINTER(EapParams), C.c_uint64, C.POINTER(EapResult), C.POINTER(EapTrace)]
             f.restype = C.c_int
         L.eap_run_many.argtypes = [C.POINTER(EapParams), C.c_uint64, C.c_int64, C.c_int, C.c_int,
@@ -98,12 +102,20 @@ def make_params(**kw) -> EapParams:
              adj_lb=0.15, adj_ub=0.55, adj_scale=1.1,
              n=100, num_steps=100000, num_inits=1, steps_per_adjust=2500, stepout=500,
              seed=0, chain_type=DIELECTRIC, energy_type=NONINTERACTING,
-             do_flips=0, force_init=0, umbrella=0, rng=RNG_MWC64X)
+             do_flips=0, force_init=0, umbrella=0, rng=RNG_MWC64X,
+             bend_mod=0.0, bend_angle=0.0, cluster_prob=1.0, x0_phi=0.0, x0_theta=0.0,
+             dx0_phi=2 * np.pi, dx0_theta=0.1, burn_in=0, burn_nsched=0, use_x0=0)
+    sched = list(kw.pop("burn_sched", []))
     unknown = set(kw) - set(d)
     if unknown:
         raise KeyError(f"unknown oracle parameter(s): {sorted(unknown)}")
     d.update(kw)
-    return EapParams(**d)
+    if sched:
+        d["burn_nsched"] = len(sched)
+    p = EapParams(**d)
+    for i, v in enumerate(sched):
+        p.burn_sched[i] = v
+    return p
 
 
 @dataclass
@@ -123,6 +135,7 @@ class Run:
     accepted: np.ndarray | None = None
     rolling: np.ndarray | None = None
     traj: np.ndarray | None = None
+    extra_sums: np.ndarray | None = None      # clustering main: sum cos^2(theta), mean psi
     extra: dict = field(default_factory=dict)
 
     @property
@@ -137,7 +150,8 @@ class Run:
 def _unpack(res: EapResult) -> Run:
     return Run(sums=np.array(res.sum[:]), norm=res.norm, nacc_total=res.nacc_total,
                nsteps_total=res.nsteps_total, phi_step=res.phi_step, theta_step=res.theta_step,
-               r=np.array(res.r[:]), p=np.array(res.p[:]), U=res.U, rng=np.array(res.rng[:], dtype=np.uint32))
+               r=np.array(res.r[:]), p=np.array(res.p[:]), U=res.U, rng=np.array(res.rng[:], dtype=np.uint32),
+               extra_sums=np.array(res.extra_sum[:]))
 
 
 def run(params: EapParams, chain_id: int = 0, mode: str = "faithful", trace: bool = False,
@@ -149,7 +163,8 @@ def run(params: EapParams, chain_id: int = 0, mode: str = "faithful", trace: boo
     if trace:
         keep["phi"] = np.zeros(params.n)
         keep["th"] = np.zeros(params.n)
-        keep["acc"] = np.zeros(max(1, params.num_inits * params.num_steps), dtype=np.uint8)
+        keep["acc"] = np.zeros(max(1, params.num_inits * params.num_steps + params.burn_nsched * params.burn_in),
+                               dtype=np.uint8)
         tr.final_phi = keep["phi"].ctypes.data_as(C.POINTER(C.c_double))
         tr.final_theta = keep["th"].ctypes.data_as(C.POINTER(C.c_double))
         tr.accepted = keep["acc"].ctypes.data_as(C.POINTER(C.c_uint8))
@@ -160,7 +175,7 @@ def run(params: EapParams, chain_id: int = 0, mode: str = "faithful", trace: boo
         tr.rolling_rows = keep["roll"].ctypes.data_as(C.POINTER(C.c_double))
         tr.traj_rows = keep["traj"].ctypes.data_as(C.POINTER(C.c_double))
         tr.max_rows = nrows
-    fn = {"faithful": L.eap_run_faithful, "fast": L.eap_run_fast}[mode]
+    fn = {"faithful": L.eap_run_faithful, "fast": L.eap_run_fast, "cluster": L.eap_run_cluster}[mode]
     rc = fn(C.byref(params), chain_id, C.byref(res), C.byref(tr))
     if rc != 0:
         raise RuntimeError(f"oracle returned {rc}")
@@ -177,7 +192,7 @@ def run_many(params: EapParams, id0: int, nchains: int, nthreads: int = 1, mode:
     """Returns (sums[nchains,16], norm[nchains], nacc[nchains]) for chain ids id0..id0+nchains-1."""
     L = lib()
     arr = (EapResult * nchains)()
-    rc = L.eap_run_many(C.byref(params), id0, nchains, nthreads, 1 if mode == "fast" else 0, arr)
+    rc = L.eap_run_many(C.byref(params), id0, nchains, nthreads, {"faithful": 0, "fast": 1, "cluster": 2}[mode], arr)
     if rc != 0:
         raise RuntimeError(f"oracle returned {rc}")
     sums = np.array([a.sum[:] for a in arr])

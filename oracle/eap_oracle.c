@@ -177,11 +177,12 @@ double eap_pair_energy(int64_t n, const double *xs, const double *mus, int ising
 
 /* ------------------------------------------------------------------ literal chain object */
 
-typedef struct chain_t { /* inc/eap_chain.jl:12-36 (psi/kappa omitted: kappa = 0 in this main, :91) */
+typedef struct chain_t { /* inc/eap_chain.jl:12-36 */
   int64_t n;
   double *phi, *cphi, *sphi, *th, *cth, *sth; /* n each      */
   double *nh, *mus, *xs;                      /* 3 x n, column-major */
-  double *us;                                 /* n           */
+  double *us;                                 /* n: u_i + bending energy of bond (i, i+1), :53-58 */
+  double *psis;                               /* n (n-1 used): bond angles, :45-47 */
   double r[3];
   double Omega;
   double U;
@@ -190,12 +191,12 @@ typedef struct chain_t { /* inc/eap_chain.jl:12-36 (psi/kappa omitted: kappa = 0
 
 static int chain_alloc(chain_t *c, int64_t n) {
   c->n = n;
-  c->block = (double *)malloc(sizeof(double) * (size_t)(16 * n));
+  c->block = (double *)malloc(sizeof(double) * (size_t)(17 * n));
   if (!c->block) return -1;
   double *q = c->block;
   c->phi = q; q += n;  c->cphi = q; q += n;  c->sphi = q; q += n;
   c->th = q;  q += n;  c->cth = q;  q += n;  c->sth = q;  q += n;
-  c->us = q;  q += n;
+  c->us = q;  q += n;  c->psis = q; q += n;
   c->nh = q;  q += 3 * n;  c->mus = q; q += 3 * n;  c->xs = q;
   return 0;
 }
@@ -203,7 +204,7 @@ static void chain_free(chain_t *c) { free(c->block); c->block = NULL; }
 
 /* EAPChain(chain::EAPChain) deep copy, eap_chain.jl:137-163 */
 static void chain_copy(chain_t *dst, const chain_t *src) {
-  memcpy(dst->block, src->block, sizeof(double) * (size_t)(16 * src->n));
+  memcpy(dst->block, src->block, sizeof(double) * (size_t)(17 * src->n));
   dst->r[0] = src->r[0]; dst->r[1] = src->r[1]; dst->r[2] = src->r[2];
   dst->Omega = src->Omega;
   dst->U = src->U;
@@ -250,12 +251,21 @@ static double chain_U(const eap_params *P, const chain_t *c) {
   return U - (r[0] * P->Fx + r[1] * 0.0 + r[2] * P->Fz);
 }
 
-static void set_monomer(const eap_params *P, chain_t *c, int64_t i) {
+static void set_nhat_mu(const eap_params *P, chain_t *c, int64_t i) {
   c->nh[3 * i]     = c->cphi[i] * c->sth[i];
   c->nh[3 * i + 1] = c->sphi[i] * c->sth[i];
   c->nh[3 * i + 2] = c->cth[i];
   eap_dipole(P, c->cphi[i], c->sphi[i], c->cth[i], c->sth[i], c->mus + 3 * i);
-  c->us[i] = -1.0 / 2.0 * P->E0 * c->mus[3 * i + 2]; /* u(), eap_chain.jl:53; ubend == 0 */
+}
+/* psi_j, eap_chain.jl:45-47: angle between monomers j and j+1 */
+static double psi_j(const chain_t *c, int64_t j) {
+  double d = c->nh[3 * j] * c->nh[3 * j + 3] + c->nh[3 * j + 1] * c->nh[3 * j + 4] + c->nh[3 * j + 2] * c->nh[3 * j + 5];
+  return acos(fmin(1, fmax(-1, d)));
+}
+/* u() + ubend(), eap_chain.jl:53-58: kappa = 0 in mcmc_eap_chain.jl (no --bend-mod there, :91) */
+static void set_u(const eap_params *P, chain_t *c, int64_t i) {
+  double ubend = (i != c->n - 1) ? P->bend_mod / 2 * (c->psis[i] - P->bend_angle) * (c->psis[i] - P->bend_angle) : 0.0;
+  c->us[i] = -1.0 / 2.0 * P->E0 * c->mus[3 * i + 2] + ubend;
 }
 
 /* derive every cached field from (phi, theta): the tail of EAPChain(pargs), eap_chain.jl:109-134 */
@@ -267,7 +277,10 @@ static void chain_derive(const eap_params *P, chain_t *c) {
     prod *= c->sth[i];
   }
   c->Omega = log(prod); /* eap_chain.jl:117 */
-  for (int64_t i = 0; i < c->n; ++i) set_monomer(P, c, i);
+  for (int64_t i = 0; i < c->n; ++i) set_nhat_mu(P, c, i);          /* :124-129 */
+  for (int64_t i = 0; i + 1 < c->n; ++i) c->psis[i] = psi_j(c, i);  /* :125 */
+  if (c->n > 0) c->psis[c->n - 1] = 0.0;
+  for (int64_t i = 0; i < c->n; ++i) set_u(P, c, i);                /* :130 */
   update_xs(P, c);
   end_to_end(P, c, c->r);
   c->U = chain_U(P, c);
@@ -275,8 +288,13 @@ static void chain_derive(const eap_params *P, chain_t *c) {
 
 /* EAPChain(pargs), eap_chain.jl:60-135: all phi draws, then all theta draws */
 static void chain_random(const eap_params *P, uint32_t rng[5], chain_t *c) {
-  for (int64_t i = 0; i < c->n; ++i) c->phi[i] = (2.0 * M_PI) * draw_u(rng);
-  for (int64_t i = 0; i < c->n; ++i) c->th[i] = M_PI * draw_u(rng);
+  if (P->use_x0) { /* eap_chain.jl:69-72: x0 = [phi; theta] plus Uniform(0, dx0) */
+    for (int64_t i = 0; i < c->n; ++i) c->phi[i] = P->x0_phi + P->dx0_phi * draw_u(rng);
+    for (int64_t i = 0; i < c->n; ++i) c->th[i] = P->x0_theta + P->dx0_theta * draw_u(rng);
+  } else {
+    for (int64_t i = 0; i < c->n; ++i) c->phi[i] = (2.0 * M_PI) * draw_u(rng);
+    for (int64_t i = 0; i < c->n; ++i) c->th[i] = M_PI * draw_u(rng);
+  }
   chain_derive(P, c);
 }
 
@@ -290,7 +308,10 @@ static void chain_move(const eap_params *P, chain_t *c, int64_t idx, double dphi
   c->Omega += log(sth / c->sth[idx]);
   c->cth[idx] = cos(c->th[idx]);
   c->sth[idx] = sth;
-  set_monomer(P, c, idx); /* n-hat, mu, u of idx (u of idx-1 is recomputed to the same value) */
+  set_nhat_mu(P, c, idx);                                    /* :243-245, "the order ... is important" */
+  if (idx < c->n - 1) c->psis[idx] = psi_j(c, idx);          /* :246 */
+  if (idx > 0) { c->psis[idx - 1] = psi_j(c, idx - 1); set_u(P, c, idx - 1); }   /* :247-250 */
+  set_u(P, c, idx);                                          /* :251 */
   update_xs(P, c);
   end_to_end(P, c, c->r);
   c->U = chain_U(P, c);
@@ -443,6 +464,7 @@ int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, ea
 
   memcpy(out->sum, A.sum, sizeof A.sum);
   out->norm = A.norm;
+  out->extra_sum[0] = out->extra_sum[1] = 0.0;
   out->nacc_total = nacc_total;
   out->nsteps_total = P->num_inits * P->num_steps;
   out->phi_step = phistep;
@@ -454,6 +476,129 @@ int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, ea
   if (tr && tr->final_phi) memcpy(tr->final_phi, cur.phi, sizeof(double) * (size_t)P->n);
   if (tr && tr->final_theta) memcpy(tr->final_theta, cur.th, sizeof(double) * (size_t)P->n);
   chain_free(&cur); chain_free(&trial); chain_free(&fresh);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ clustering main */
+
+/* cluster_flip!, inc/eap_chain.jl:269-333 (flip_f! = refl_n!, pflip = pflip_linear) */
+static double cluster_flip(const eap_params *P, uint32_t rng[5], chain_t *c, int64_t idx) {
+  if (draw_u(rng) <= P->cluster_prob) return 1.0;                                  /* :276 */
+  const int64_t n = c->n;
+  double upper_p, lower_p;
+  int64_t upper = idx, lower = idx;
+  for (;;) {                                                                        /* :281-292 */
+    if (upper >= n - 1) { upper_p = 0.0; break; }
+    double d = c->nh[3 * upper] * c->nh[3 * upper + 3] + c->nh[3 * upper + 1] * c->nh[3 * upper + 4] +
+               c->nh[3 * upper + 2] * c->nh[3 * upper + 5];
+    upper_p = (1 + d) / 2;
+    if (draw_u(rng) <= upper_p) ++upper; else break;
+  }
+  for (;;) {                                                                        /* :298-309 */
+    if (lower <= 0) { lower_p = 0.0; break; }
+    double d = c->nh[3 * lower] * c->nh[3 * lower - 3] + c->nh[3 * lower + 1] * c->nh[3 * lower - 2] +
+               c->nh[3 * lower + 2] * c->nh[3 * lower - 1];
+    lower_p = (1 + d) / 2;
+    if (draw_u(rng) <= lower_p) --lower; else break;
+  }
+  for (int64_t i = lower; i <= upper; ++i) chain_move(P, c, i, 0.0, M_PI - 2 * c->th[i]);  /* refl_n!, :263-265,314-316 */
+  double new_upper_p = 0.0, new_lower_p = 0.0;                                      /* :318-327 */
+  if (upper < n - 1)
+    new_upper_p = (1 + (c->nh[3 * upper] * c->nh[3 * upper + 3] + c->nh[3 * upper + 1] * c->nh[3 * upper + 4] +
+                        c->nh[3 * upper + 2] * c->nh[3 * upper + 5])) / 2;
+  if (lower > 0)
+    new_lower_p = (1 + (c->nh[3 * lower] * c->nh[3 * lower - 3] + c->nh[3 * lower + 1] * c->nh[3 * lower - 2] +
+                        c->nh[3 * lower + 2] * c->nh[3 * lower - 1])) / 2;
+  return ((1 - new_upper_p) * (1 - new_lower_p)) / ((1 - upper_p) * (1 - lower_p));
+}
+
+static void record_extra(double ex[2], const chain_t *c, int umbrella, double w) {
+  double c2 = 0.0, ps = 0.0;
+  for (int64_t i = 0; i < c->n; ++i) c2 += c->cth[i] * c->cth[i];   /* :243 */
+  for (int64_t i = 0; i + 1 < c->n; ++i) ps += c->psis[i];
+  ps /= (double)(c->n - 1);                                           /* :244 */
+  double expw = umbrella ? exp(w) : 1.0;
+  ex[0] += umbrella ? c2 / expw : c2;
+  ex[1] += umbrella ? ps / expw : ps;
+}
+
+/* one call of mcmc(nsteps, pargs, chain), mcmc_clustering_eap_chain.jl:172-352 */
+static void cluster_stage(const eap_params *P, int64_t nsteps, uint32_t rng[5], chain_t *cur, chain_t *trial,
+                          averagers_t *A, double extra[2], int64_t *nacc_total_out, double steps_out[2],
+                          eap_trace *tr, int64_t *t) {
+  double phistep = P->phi_step, thstep = P->theta_step;           /* :174 */
+  cur->U = chain_U(P, cur);                                       /* :177 */
+  weight_t wf = weight_make(P, cur->Omega);                       /* :178 */
+  double logpi_prev = -cur->U / P->kT + cur->Omega + (wf.on ? weight_eval(&wf, sum_us(cur)) : 1.0);
+  memset(A, 0, sizeof *A);
+  extra[0] = extra[1] = 0.0;
+  int64_t nacc = 0, natt = 0, nacc_total = 0;
+  for (int64_t step = 1; step <= nsteps; ++step, ++*t) {          /* :268 */
+    int64_t idx = draw_idx(rng, P->n);
+    double dphi = phistep * (2.0 * draw_u(rng) - 1.0);
+    double dth = thstep * (2.0 * draw_u(rng) - 1.0);
+    chain_copy(trial, cur);
+    chain_move(P, trial, idx, dphi, dth);                         /* :272 */
+    double alpha = cluster_flip(P, rng, trial, idx);              /* :273 */
+    double eps = draw_u(rng);
+    /* acceptance.jl:29-39 with alpha; the cached value keeps the log(alpha) of the accepted move */
+    double logpi = -trial->U / P->kT + trial->Omega + (wf.on ? weight_eval(&wf, sum_us(trial)) : 1.0) + log(alpha);
+    int ok = (logpi >= logpi_prev) || (eps < exp(logpi - logpi_prev));
+    if (ok) {
+      logpi_prev = logpi;
+      chain_t tmp = *cur; *cur = *trial; *trial = tmp;
+      ++nacc; ++nacc_total;
+    }
+    ++natt;
+    if (tr && tr->accepted) tr->accepted[*t] = (uint8_t)ok;
+    adapt(P, step, &phistep, &thstep, &nacc, &natt);              /* :287-308 */
+    double p[3];
+    chain_mu(cur, p);
+    double w = wf.on ? weight_eval(&wf, sum_us(cur)) : 1.0;
+    record(A, cur->r, p, cur->U, P->umbrella, w);                 /* :310-311 */
+    record_extra(extra, cur, P->umbrella, w);
+    if (P->stepout > 0 && step % P->stepout == 0) emit_rows(tr, step, A, cur->r, p, cur->U);
+  }
+  *nacc_total_out = nacc_total;
+  steps_out[0] = phistep; steps_out[1] = thstep;
+}
+
+int eap_run_cluster(const eap_params *P0, uint64_t chain_id, eap_result *out, eap_trace *tr) {
+  if (check_params(P0)) return -1;
+  if (P0->burn_nsched < 0 || P0->burn_nsched > 8) return -1;
+  uint32_t rng[5];
+  seed_chain(P0, chain_id, rng);
+  chain_t cur, trial;
+  if (chain_alloc(&cur, P0->n) || chain_alloc(&trial, P0->n)) return -2;
+  if (tr) tr->rows_written = 0;
+  eap_params P = *P0;
+  averagers_t A;
+  double extra[2], steps[2] = {P0->phi_step, P0->theta_step};
+  int64_t nacc_total = 0, t = 0;
+  chain_random(&P, rng, &cur);                                    /* mcmc(nsteps, pargs): EAPChain(pargs), :167-170 */
+  /* burn-in ladder, :365-386: every rung is a fresh mcmc() call (fresh acceptor, averagers, step sizes) */
+  for (int s = 0; s < P0->burn_nsched; ++s) {
+    P.kT = P0->kT * P0->burn_sched[s];
+    if (tr) tr->rows_written = 0;                                 /* each call rewrites the CSV files */
+    cluster_stage(&P, P0->burn_in, rng, &cur, &trial, &A, extra, &nacc_total, steps, tr, &t);
+  }
+  P.kT = P0->kT;
+  if (tr) tr->rows_written = 0;
+  cluster_stage(&P, P0->num_steps, rng, &cur, &trial, &A, extra, &nacc_total, steps, tr, &t);
+
+  memcpy(out->sum, A.sum, sizeof A.sum);
+  out->norm = A.norm;
+  out->extra_sum[0] = extra[0]; out->extra_sum[1] = extra[1];
+  out->nacc_total = nacc_total;
+  out->nsteps_total = P0->num_steps;
+  out->phi_step = steps[0]; out->theta_step = steps[1];
+  memcpy(out->r, cur.r, sizeof cur.r);
+  chain_mu(&cur, out->p);
+  out->U = cur.U;
+  memcpy(out->rng, rng, sizeof out->rng);
+  if (tr && tr->final_phi) memcpy(tr->final_phi, cur.phi, sizeof(double) * (size_t)P0->n);
+  if (tr && tr->final_theta) memcpy(tr->final_theta, cur.th, sizeof(double) * (size_t)P0->n);
+  chain_free(&cur); chain_free(&trial);
   return 0;
 }
 
@@ -636,6 +781,7 @@ int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_tr
 
   memcpy(out->sum, A.sum, sizeof A.sum);
   out->norm = A.norm;
+  out->extra_sum[0] = out->extra_sum[1] = 0.0;
   out->nacc_total = nacc_total;
   out->nsteps_total = P->num_inits * P->num_steps;
   out->phi_step = phistep; out->theta_step = thstep;
@@ -676,8 +822,9 @@ static void *farm_worker(void *arg) {
     int64_t k = F->next++;
     pthread_mutex_unlock(&F->mu);
     if (k >= F->nchains) break;
-    int rc = F->mode ? eap_run_fast(F->P, F->id0 + (uint64_t)k, F->out + k, NULL)
-                     : eap_run_faithful(F->P, F->id0 + (uint64_t)k, F->out + k, NULL);
+    int rc = F->mode == 2 ? eap_run_cluster(F->P, F->id0 + (uint64_t)k, F->out + k, NULL)
+           : F->mode      ? eap_run_fast(F->P, F->id0 + (uint64_t)k, F->out + k, NULL)
+                          : eap_run_faithful(F->P, F->id0 + (uint64_t)k, F->out + k, NULL);
     if (rc) F->err = rc;
   }
   return NULL;

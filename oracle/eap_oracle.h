@@ -45,6 +45,15 @@ typedef struct eap_params {
   int32_t force_init;
   int32_t umbrella;
   int32_t rng;          /* EAP_RNG_MWC64X | EAP_RNG_XOSHIRO128PP */
+  /* --- options that only mcmc_clustering_eap_chain.jl has (eap_run_cluster); zero = absent --- */
+  double bend_mod, bend_angle;          /* --bend-mod, --bend-angle (:36-43; inc/eap_chain.jl:54-58,91-92) */
+  double cluster_prob;                  /* --cluster-prob (:87-90): probability of NOT attempting a cluster flip */
+  double x0_phi, x0_theta;              /* --x0 "[phi; theta]" (:142-144; inc/eap_chain.jl:61-72) */
+  double dx0_phi, dx0_theta;            /* --dx0 (:145-148) */
+  double burn_sched[8];                 /* --burn-schedule kT multipliers (:138-141) */
+  int64_t burn_in;                      /* --burn-in steps per rung (:134-137) */
+  int32_t burn_nsched;                  /* number of rungs used */
+  int32_t use_x0;
 } eap_params;
 
 /* Index order = the rolling.csv columns after "step" (mcmc_eap_chain.jl:259). */
@@ -62,6 +71,8 @@ typedef struct eap_result {
   double phi_step, theta_step; /* step sizes after the last adaptation      */
   double r[3], p[3], U;   /* final microstate (trajectory.csv columns)      */
   uint32_t rng[4];        /* final generator state                          */
+  double extra_sum[2];    /* clustering main only: sum cos^2(theta_i) and mean bond angle psi
+                             (mcmc_clustering_eap_chain.jl:243-244) */
 } eap_result;
 
 /* Optional per-run outputs; any pointer may be NULL. */
@@ -92,10 +103,15 @@ int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, ea
  * non-interacting/Ising and in-place update + pair recompute for interacting. */
 int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_trace *tr);
 
+/* The literal algorithm of mcmc_clustering_eap_chain.jl (single-monomer move followed by
+ * cluster_flip!, inc/eap_chain.jl:269-333; bending energy; burn-in on a temperature ladder,
+ * :365-386).  Energy types: noninteracting, Ising, interacting. */
+int eap_run_cluster(const eap_params *P, uint64_t chain_id, eap_result *out, eap_trace *tr);
+
 /* Many independent chains (chain ids id0 .. id0+nchains-1), one per worker
  * thread at a time, mirroring the reference's pmap process farm. mode: 0 faithful, 1 fast. */
 int eap_run_many(const eap_params *P, uint64_t id0, int64_t nchains, int nthreads,
-                 int mode, eap_result *out /* [nchains] */);
+                 int mode /* 0 faithful, 1 fast, 2 clustering main */, eap_result *out /* [nchains] */);
 
 /* Building blocks exported for hand-computable tests. */
 void eap_dipole(const eap_params *P, double cphi, double sphi, double cth, double sth,
