@@ -8,7 +8,7 @@ Workload (BASELINE.json configs[1]): non-interacting dielectric chain, n = 100, 
 K2 = 0, kT = 1, b = 1, one point of the Fz sweep per bench step, 65 536 chains per GPU, 1e5 MC steps
 per chain (6.55e9 attempted monomer updates per GPU per step).  Weak scaling: every rank runs its own
 65 536 chains (global chain ids rank*65536 ...), no data-path collective; the only exchange is one
-RCCL all-reduce of the 35-double reduction vector per step.
+RCCL all-reduce of the 39-double reduction vector per step.
 
 A bench "step" = advance every chain of one Fz point by --mc-steps Monte-Carlo steps (ONE launch of
 the sweep kernel) + the on-device reduction + the all-reduce.  Chain states are created (on the

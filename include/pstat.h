@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PSTAT_ABI_VERSION 2
+#define PSTAT_ABI_VERSION 3
 
 typedef enum pstat_status {
   PSTAT_OK = 0,
@@ -55,6 +55,12 @@ enum { PSTAT_F32 = 0, PSTAT_F64 = 1, PSTAT_Q16 = 2 };
  *   PSTAT_RNG_MWC64X        multiply-with-carry MWC64X, streams split by 2^40-output skip-ahead (default)
  *   PSTAT_RNG_XOSHIRO128PP  xoshiro128++ seeded per chain through Philox4x32-10 */
 enum { PSTAT_RNG_MWC64X = 0, PSTAT_RNG_XOSHIRO128PP = 1 };
+/* which main's step is run:
+ *   PSTAT_MOVES_SINGLE   mcmc_eap_chain.jl:276-291 -- one single-monomer trial move per step (default)
+ *   PSTAT_MOVES_CLUSTER  mcmc_clustering_eap_chain.jl:268-279 -- the same move followed, on the trial
+ *                        chain, by cluster_flip! (inc/eap_chain.jl:269-333); bending energy; two more
+ *                        averagers (sum cos^2 theta, mean bond angle).  Non-interacting and Ising. */
+enum { PSTAT_MOVES_SINGLE = 0, PSTAT_MOVES_CLUSTER = 1 };
 
 /* Flattened pargs::Dict (mcmc_eap_chain.jl:155) -- the keys the force-ensemble step loop reads. */
 typedef struct pstat_params {
@@ -75,7 +81,14 @@ typedef struct pstat_params {
   int32_t precision;     /* PSTAT_F32 | PSTAT_F64 | PSTAT_Q16                                 */
   int32_t device;        /* HIP device ordinal                                                */
   int32_t rng;           /* PSTAT_RNG_MWC64X | PSTAT_RNG_XOSHIRO128PP                         */
-  int32_t reserved;      /* must be 0                                                         */
+  int32_t move_set;      /* PSTAT_MOVES_SINGLE | PSTAT_MOVES_CLUSTER                          */
+  /* options of mcmc_clustering_eap_chain.jl (:36-43,87-90,142-148); all 0 in mcmc_eap_chain.jl */
+  double bend_mod, bend_angle;   /* --bend-mod, --bend-angle (per case)                       */
+  double cluster_prob;           /* --cluster-prob (per case)                                 */
+  double x0_phi, x0_theta;       /* --x0 "[phi; theta]"                                       */
+  double dx0_phi, dx0_theta;     /* --dx0                                                     */
+  int32_t use_x0;                /* start from x0 + Uniform(0, dx0) instead of uniform angles */
+  int32_t reserved;              /* must be 0                                                 */
 } pstat_params;
 
 /* Order of every 16-vector below = the columns of <prefix>_rolling.csv after "step"
@@ -88,11 +101,13 @@ enum {
 
 /* Length (in doubles) of the device-side reduction vector of pstat_reduce_device():
  *   [0]        number of chains reduced
- *   [1..17]    sum over chains of the per-chain running mean of the 16 observables, then of the
- *              per-chain acceptance ratio
- *   [18..34]   sum over chains of the squares of those per-chain means
+ *   [1..19]    sum over chains of the per-chain running mean of: the 16 observables, the per-chain
+ *              acceptance ratio, sum_i cos^2(theta_i), the mean bond angle (the last two are recorded
+ *              by the clustering main only, mcmc_clustering_eap_chain.jl:243-244)
+ *   [20..38]   sum over chains of the squares of those per-chain means
  * Every entry is additive across handles/GPUs, so one all-reduce(SUM) merges ensembles. */
-#define PSTAT_NRED 35
+#define PSTAT_NQ 19
+#define PSTAT_NRED (1 + 2 * PSTAT_NQ)
 
 /* The ten stdout quantities of mcmc_eap_chain.jl:386-395 plus bookkeeping. */
 typedef struct pstat_summary {
@@ -103,6 +118,8 @@ typedef struct pstat_summary {
   int64_t num_chains;
   int64_t steps_per_chain;     /* steps recorded so far by every chain                          */
   double attempted_updates;    /* num_chains * steps_per_chain                                  */
+  double extra_avg[2];         /* <sum cos^2 theta>, <psi> (clustering main: "<cos2(theta)>", "<psi>") */
+  double extra_stderr[2];
 } pstat_summary;
 
 typedef struct pstat_handle pstat_handle;
@@ -144,6 +161,10 @@ int pstat_reinit(pstat_handle *h, int32_t force_init);
  * depend on kT). */
 int pstat_reset_averages(pstat_handle *h);
 int pstat_set_kT(pstat_handle *h, int32_t icase, double kT);
+/* What a fresh call of the reference's mcmc(nsteps, pargs, chain) resets besides the averagers
+ * (mcmc_clustering_eap_chain.jl:172-181,263-266): step sizes back to --phi-step/--theta-step, the
+ * adaptation counters, the acceptor's cache, the in-run step counter.  The chains are kept. */
+int pstat_reset_sampler(pstat_handle *h);
 
 /* Device-side reduction over the chains of case `icase` (or over all cases if icase < 0) into
  * `dev_out`, a DEVICE pointer to PSTAT_NRED doubles owned by the caller (e.g. a torch tensor that
@@ -182,6 +203,9 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles /* [2n] */,
 
 /* Checkpoint / resume of the full device state (angles, generators, step sizes, counters, running
  * sums).  Call with buf == NULL to get the size.  The reference has no equivalent. */
+/* The clustering main's two extra averagers for one chain: their running sums and their value in
+ * the current configuration (sum cos^2 theta; mean bond angle). */
+int pstat_chain_extras(pstat_handle *h, int64_t chain, double extra_sums[2], double extra_now[2]);
 int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes);
 int pstat_restore(pstat_handle *h, const void *buf, size_t bytes);
 

@@ -22,7 +22,10 @@ struct PstatParams
   steps_per_adjust::Int64; n::Int64; num_chains::Int64
   seed::UInt64; chain_id0::UInt64
   chain_type::Int32; energy_type::Int32; do_flips::Int32; umbrella::Int32; precision::Int32; device::Int32
-  rng::Int32; reserved::Int32
+  rng::Int32; move_set::Int32
+  bend_mod::Cdouble; bend_angle::Cdouble; cluster_prob::Cdouble
+  x0_phi::Cdouble; x0_theta::Cdouble; dx0_phi::Cdouble; dx0_theta::Cdouble
+  use_x0::Int32; reserved::Int32
 end
 
 # mirror of `pstat_summary`
@@ -30,6 +33,7 @@ struct PstatSummary
   avg::NTuple{16,Cdouble}; stderr::NTuple{16,Cdouble}
   acceptance_ratio::Cdouble; ar_stderr::Cdouble
   num_chains::Int64; steps_per_chain::Int64; attempted_updates::Cdouble
+  extra_avg::NTuple{2,Cdouble}; extra_stderr::NTuple{2,Cdouble}
 end
 
 function check(rc::Cint)
@@ -111,12 +115,15 @@ function params(pargs, num_chains, chain_id0, device)
               pargs["mlen"], pargs["phi-step"], pargs["theta-step"], pargs["step-adjust-lb"],
               pargs["step-adjust-ub"], pargs["step-adjust-scale"], pargs["steps-per-adjust"],
               pargs["num-monomers"], num_chains, UInt64(pargs["seed"]), UInt64(chain_id0),
-              ct, et, pargs["do-flips"] ? 1 : 0, pargs["umbrella-sampling"] ? 1 : 0, prec, device, rng, 0)
+              ct, et, pargs["do-flips"] ? 1 : 0, pargs["umbrella-sampling"] ? 1 : 0, prec, device, rng,
+              0,                                   # move_set = PSTAT_MOVES_SINGLE: this main
+              0.0, 0.0, 0.5, 0.0, 0.0, 2pi, 0.1,   # clustering-main options at their defaults (unused here)
+              0, 0)
 end
 
 function pooled_summary(handles, steps)
-  red = zeros(Cdouble, 35)
-  tmp = zeros(Cdouble, 35)
+  red = zeros(Cdouble, 39)
+  tmp = zeros(Cdouble, 39)
   for h in handles
     check(ccall((:pstat_reduce_host, LIBPSTAT), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}), h, -1, tmp))
     red .+= tmp

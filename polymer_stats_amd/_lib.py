@@ -13,7 +13,9 @@ NONINTERACTING, INTERACTING, ISING = 0, 1, 2
 F32, F64, Q16 = 0, 1, 2
 RNG_MWC64X, RNG_XOSHIRO128PP = 0, 1
 NOBS = 16
-NRED = 35
+NQ = 19
+NRED = 1 + 2 * NQ
+MOVES_SINGLE, MOVES_CLUSTER = 0, 1
 OBS_NAMES = ["r1", "r2", "r3", "r1sq", "r2sq", "r3sq", "rsq",
              "p1", "p2", "p3", "p1sq", "p2sq", "p3sq", "psq", "U", "Usq"]
 
@@ -21,8 +23,8 @@ OBS_NAMES = ["r1", "r2", "r3", "r1sq", "r2sq", "r3sq", "rsq",
 SYMBOLS = [
     "pstat_abi_version", "pstat_strerror", "pstat_last_error", "pstat_device_count",
     "pstat_default_params", "pstat_create", "pstat_destroy", "pstat_advance", "pstat_sync",
-    "pstat_reinit", "pstat_reset_averages", "pstat_set_kT", "pstat_reduce_device", "pstat_reduce_host", "pstat_rolling", "pstat_microstate",
-    "pstat_summary_get", "pstat_summary_from_reduction", "pstat_chain_state",
+    "pstat_reinit", "pstat_reset_averages", "pstat_set_kT", "pstat_reset_sampler", "pstat_reduce_device", "pstat_reduce_host", "pstat_rolling", "pstat_microstate",
+    "pstat_summary_get", "pstat_summary_from_reduction", "pstat_chain_state", "pstat_chain_extras",
     "pstat_checkpoint", "pstat_restore", "pstat_launch_info_get",
 ]
 
@@ -40,14 +42,18 @@ class Params(C.Structure):
                [("steps_per_adjust", C.c_int64), ("n", C.c_int64), ("num_chains", C.c_int64),
                 ("seed", C.c_uint64), ("chain_id0", C.c_uint64)] + \
                [(k, C.c_int32) for k in
-                ("chain_type", "energy_type", "do_flips", "umbrella", "precision", "device", "rng", "reserved")]
+                ("chain_type", "energy_type", "do_flips", "umbrella", "precision", "device", "rng", "move_set")] + \
+               [(k, C.c_double) for k in
+                ("bend_mod", "bend_angle", "cluster_prob", "x0_phi", "x0_theta", "dx0_phi", "dx0_theta")] + \
+               [("use_x0", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Summary(C.Structure):
     _fields_ = [("avg", C.c_double * NOBS), ("stderr", C.c_double * NOBS),
                 ("acceptance_ratio", C.c_double), ("ar_stderr", C.c_double),
                 ("num_chains", C.c_int64), ("steps_per_chain", C.c_int64),
-                ("attempted_updates", C.c_double)]
+                ("attempted_updates", C.c_double),
+                ("extra_avg", C.c_double * 2), ("extra_stderr", C.c_double * 2)]
 
 
 class LaunchInfo(C.Structure):
@@ -84,6 +90,8 @@ def load():
     L.pstat_reinit.argtypes = [vp, i32]
     L.pstat_reset_averages.argtypes = [vp]
     L.pstat_set_kT.argtypes = [vp, i32, C.c_double]
+    L.pstat_reset_sampler.argtypes = [vp]
+    L.pstat_chain_extras.argtypes = [vp, i64, dp, dp]
     L.pstat_reduce_device.argtypes = [vp, i32, vp]
     L.pstat_reduce_host.argtypes = [vp, i32, dp]
     L.pstat_rolling.argtypes = [vp, i32, dp, dp]

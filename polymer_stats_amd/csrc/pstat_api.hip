@@ -94,6 +94,20 @@ int validate(const pstat_params *c, int ncases) {
   if (b.rng != PSTAT_RNG_MWC64X && b.rng != PSTAT_RNG_XOSHIRO128PP)
     return fail(PSTAT_ERR_INVALID_ARG, "rng must be PSTAT_RNG_MWC64X or PSTAT_RNG_XOSHIRO128PP");
   if (b.reserved != 0) return fail(PSTAT_ERR_INVALID_ARG, "reserved field must be 0");
+  if (b.move_set != PSTAT_MOVES_SINGLE && b.move_set != PSTAT_MOVES_CLUSTER)
+    return fail(PSTAT_ERR_INVALID_ARG, "move_set must be PSTAT_MOVES_SINGLE or PSTAT_MOVES_CLUSTER");
+  if (b.move_set == PSTAT_MOVES_CLUSTER) {
+    if (b.energy_type == PSTAT_INTERACTING)
+      return fail(PSTAT_ERR_UNSUPPORTED, "cluster moves are implemented for energy-type noninteracting and Ising");
+    if (b.precision == PSTAT_Q16)
+      return fail(PSTAT_ERR_UNSUPPORTED, "cluster moves are not implemented for the lattice state (PSTAT_Q16)");
+    if (b.do_flips) return fail(PSTAT_ERR_INVALID_ARG, "mcmc_clustering_eap_chain.jl has no --do-flips");
+    if (b.n < 2) return fail(PSTAT_ERR_INVALID_ARG, "cluster moves need num-monomers >= 2 (the mean bond angle)");
+  }
+  if (b.use_x0 != 0 && b.use_x0 != 1) return fail(PSTAT_ERR_INVALID_ARG, "use_x0 must be 0 or 1");
+  if (b.use_x0 && (!std::isfinite(b.x0_phi) || !std::isfinite(b.x0_theta) || !std::isfinite(b.dx0_phi) ||
+                   !std::isfinite(b.dx0_theta)))
+    return fail(PSTAT_ERR_INVALID_ARG, "non-finite x0 / dx0");
   if (!(b.phi_step > 0) || !(b.theta_step > 0))
     return fail(PSTAT_ERR_INVALID_ARG, "phi-step and theta-step must be > 0");
   if (!(b.adj_scale > 0)) return fail(PSTAT_ERR_INVALID_ARG, "step-adjust-scale must be > 0");
@@ -101,16 +115,29 @@ int validate(const pstat_params *c, int ncases) {
     const pstat_params &p = c[i];
     if (!(p.kT > 0)) return fail(PSTAT_ERR_INVALID_ARG, "kT must be > 0 (case %d)", i);
     if (!std::isfinite(p.E0) || !std::isfinite(p.K1) || !std::isfinite(p.K2) || !std::isfinite(p.mu) ||
-        !std::isfinite(p.Fz) || !std::isfinite(p.Fx) || !std::isfinite(p.b))
+        !std::isfinite(p.Fz) || !std::isfinite(p.Fx) || !std::isfinite(p.b) || !std::isfinite(p.bend_mod) ||
+        !std::isfinite(p.bend_angle))
       return fail(PSTAT_ERR_INVALID_ARG, "non-finite physics parameter (case %d)", i);
+    if (!(p.cluster_prob >= 0.0 && p.cluster_prob <= 1.0) && b.move_set == PSTAT_MOVES_CLUSTER)
+      return fail(PSTAT_ERR_INVALID_ARG, "cluster-prob must be in [0, 1] (case %d)", i);
+    if (b.move_set == PSTAT_MOVES_SINGLE && p.bend_mod != 0.0)
+      return fail(PSTAT_ERR_INVALID_ARG, "bend-mod belongs to the clustering main (move_set = PSTAT_MOVES_CLUSTER)");
     if (p.n != b.n || p.num_chains != b.num_chains || p.chain_type != b.chain_type ||
         p.energy_type != b.energy_type || p.do_flips != b.do_flips || p.umbrella != b.umbrella ||
         p.precision != b.precision || p.device != b.device || p.rng != b.rng || p.phi_step != b.phi_step ||
         p.theta_step != b.theta_step || p.adj_lb != b.adj_lb || p.adj_ub != b.adj_ub ||
-        p.adj_scale != b.adj_scale || p.steps_per_adjust != b.steps_per_adjust)
+        p.adj_scale != b.adj_scale || p.steps_per_adjust != b.steps_per_adjust || p.move_set != b.move_set ||
+        p.use_x0 != b.use_x0 || p.x0_phi != b.x0_phi || p.x0_theta != b.x0_theta || p.dx0_phi != b.dx0_phi ||
+        p.dx0_theta != b.dx0_theta)
       return fail(PSTAT_ERR_INVALID_ARG, "case %d differs from case 0 in a non-physics field", i);
   }
   return PSTAT_OK;
+}
+
+// attributes of the chain-per-lane kernel that runs this handle's steps
+hipError_t kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds, int *bpc, const char **name) {
+  return cfg.move_set == PSTAT_MOVES_CLUSTER ? cluster_kernel_info(cfg, a, lds, bpc, name)
+                                             : sweep_kernel_info(cfg, a, lds, bpc, name);
 }
 
 int set_device(pstat_handle *h) {
@@ -169,6 +196,10 @@ void pstat_default_params(pstat_params *p) {
   p->do_flips = 0; p->umbrella = 0;
   p->precision = PSTAT_F32; p->device = 0;
   p->rng = PSTAT_RNG_MWC64X; p->reserved = 0;
+  // mcmc_clustering_eap_chain.jl:36-43,87-90,142-148 (only read when move_set = PSTAT_MOVES_CLUSTER / use_x0)
+  p->move_set = PSTAT_MOVES_SINGLE;
+  p->bend_mod = 0.0; p->bend_angle = 0.0; p->cluster_prob = 0.5;
+  p->use_x0 = 0; p->x0_phi = 0.0; p->x0_theta = 0.0; p->dx0_phi = 2 * M_PI; p->dx0_theta = 1e-1;
 }
 
 int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_handle **out) {
@@ -189,12 +220,13 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   h->elem = cases[0].precision == PSTAT_F64 ? 8 : (cases[0].precision == PSTAT_Q16 ? 2 : 4);
   for (int i = 0; i < ncases; ++i) {
     const pstat_params &p = cases[i];
-    h->cases.push_back({p.E0, p.K1, p.K2, p.mu, p.kT, p.Fz, p.Fx, p.b, p.seed, p.chain_id0});
+    h->cases.push_back({p.E0, p.K1, p.K2, p.mu, p.kT, p.Fz, p.Fx, p.b, p.seed, p.chain_id0,
+                        p.bend_mod, p.bend_angle, p.cluster_prob});
   }
   bool any_fx = false;
   for (auto &c : h->cases) any_fx = any_fx || c.Fx != 0.0;
   h->cfg = {h->base.precision, h->base.chain_type, h->base.energy_type, h->base.do_flips ? 1 : 0,
-            h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, 0, h->base.rng};
+            h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, 0, h->base.rng, h->base.move_set};
 
   const bool inter = h->base.energy_type == PSTAT_INTERACTING;
   int lanes = inter ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
@@ -248,7 +280,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
       SweepArgs probe = h->args;
       probe.lanes = cand;
       int lds = 0, bpc = 0;
-      if (sweep_kernel_info(h->cfg, probe, &lds, &bpc, nullptr) != hipSuccess || bpc < 1) continue;
+      if (kernel_info(h->cfg, probe, &lds, &bpc, nullptr) != hipSuccess || bpc < 1) continue;
       const double slots = (double)bpc * prop.multiProcessorCount;
       const double wgs = (double)ncases * (double)((h->base.num_chains + cand - 1) / cand);
       double cost = wgs / slots;
@@ -291,7 +323,8 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_HIP(hipMemsetAsync(h->d_queue, 0, sizeof(int) * sweep_queue_ints(h->args), h->stream));
   CREATE_HIP(hipMemcpyAsync(h->d_cases, h->cases.data(), sizeof(CaseConst) * (size_t)ncases,
                             hipMemcpyHostToDevice, h->stream));
-  CREATE_HIP(launch_init(h->cfg, h->args, h->S, h->d_cases, h->base.phi_step, h->base.theta_step, h->stream));
+  const InitOpts io{h->base.use_x0, h->base.x0_phi, h->base.x0_theta, h->base.dx0_phi, h->base.dx0_theta};
+  CREATE_HIP(launch_init(h->cfg, h->args, h->S, h->d_cases, h->base.phi_step, h->base.theta_step, io, h->stream));
   if (inter) {  // a zero-step launch derives r, p, U (with the pair energy) from the fresh angles
     h->args.nsteps = 0; h->args.step0 = 0;
     CREATE_HIP(launch_interacting(h->cfg, h->args, h->S, h->d_cases, 0, h->stream));
@@ -300,7 +333,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   if (!inter) {
     int lds = 0, bpc = 0;
     hipDeviceProp_t prop;
-    CREATE_HIP(sweep_kernel_info(h->cfg, h->args, &lds, &bpc, nullptr));
+    CREATE_HIP(kernel_info(h->cfg, h->args, &lds, &bpc, nullptr));
     CREATE_HIP(hipGetDeviceProperties(&prop, h->device));
     h->slots = (bpc > 0 ? bpc : 1) * prop.multiProcessorCount;
   }
@@ -368,7 +401,10 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
     h->args.seg_len = (len + nseg - 1) / nseg;
     const int64_t jobs = blocks * nseg;
     const unsigned grid = (unsigned)(jobs < h->slots ? jobs : h->slots);
-    HIP_TRY(launch_sweep(h->cfg, h->args, h->S, h->d_cases, h->d_queue, grid, h->stream));
+    if (h->cfg.move_set == PSTAT_MOVES_CLUSTER)
+      HIP_TRY(launch_cluster(h->cfg, h->args, h->S, h->d_cases, h->d_queue, grid, h->stream));
+    else
+      HIP_TRY(launch_sweep(h->cfg, h->args, h->S, h->d_cases, h->d_queue, grid, h->stream));
     h->step_in_init += len;
     h->steps_recorded += len;
     nsteps -= len;
@@ -400,6 +436,8 @@ int pstat_sync(pstat_handle *h) {
 
 int pstat_reinit(pstat_handle *h, int32_t force_init) {
   if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  if (h->cfg.move_set == PSTAT_MOVES_CLUSTER)
+    return fail(PSTAT_ERR_UNSUPPORTED, "mcmc_clustering_eap_chain.jl has no --num-inits: nothing to re-initialise");
   int rc = set_device(h);
   if (rc) return rc;
   if (h->base.energy_type == PSTAT_INTERACTING) {   // done inside the one-chain-per-wave kernel
@@ -424,6 +462,15 @@ int pstat_reset_averages(pstat_handle *h) {
   HIP_TRY(hipMemsetAsync(h->S.wnorm, 0, C * sizeof(double), h->stream));
   HIP_TRY(hipMemsetAsync(h->S.nacc_total, 0, C * sizeof(int64_t), h->stream));
   h->steps_recorded = 0;
+  return PSTAT_OK;
+}
+
+int pstat_reset_sampler(pstat_handle *h) {
+  if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(launch_reset_sampler(h->S, h->base.phi_step, h->base.theta_step, h->stream));
+  h->step_in_init = 0;
   return PSTAT_OK;
 }
 
@@ -466,15 +513,16 @@ int pstat_summary_from_reduction(const double red[PSTAT_NRED], int64_t steps_per
   out->steps_per_chain = steps_per_chain;
   out->attempted_updates = C * (double)steps_per_chain;
   if (C < 1) return PSTAT_OK;
-  for (int q = 0; q < 17; ++q) {
+  for (int q = 0; q < PSTAT_NQ; ++q) {
     const double mean = red[1 + q] / C;
     double se = 0.0;
     if (C > 1) {
-      double var = (red[18 + q] / C - mean * mean) * C / (C - 1);  // unbiased across-chain variance
+      double var = (red[1 + PSTAT_NQ + q] / C - mean * mean) * C / (C - 1);  // unbiased across-chain variance
       se = var > 0 ? std::sqrt(var / C) : 0.0;
     }
     if (q < PSTAT_NOBS) { out->avg[q] = mean; out->stderr_[q] = se; }
-    else { out->acceptance_ratio = mean; out->ar_stderr = se; }
+    else if (q == PSTAT_NOBS) { out->acceptance_ratio = mean; out->ar_stderr = se; }
+    else { out->extra_avg[q - PSTAT_NOBS - 1] = mean; out->extra_stderr[q - PSTAT_NOBS - 1] = se; }
   }
   return PSTAT_OK;
 }
@@ -562,6 +610,24 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sum
   return PSTAT_OK;
 }
 
+int pstat_chain_extras(pstat_handle *h, int64_t chain, double extra_sums[2], double extra_now[2]) {
+  if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  if (chain < 0 || chain >= h->S.C) return fail(PSTAT_ERR_INVALID_ARG, "chain out of range");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const size_t C = (size_t)h->S.C;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (extra_sums)
+    HIP_TRY(hipMemcpy2D(extra_sums, sizeof(double), h->S.sums + (size_t)S_C2 * C + chain, C * sizeof(double),
+                        sizeof(double), 2, hipMemcpyDeviceToHost));
+  if (extra_now) {
+    HIP_TRY(hipMemcpy2D(extra_now, sizeof(double), h->S.obs + (size_t)OBS_C2 * C + chain, C * sizeof(double),
+                        sizeof(double), 2, hipMemcpyDeviceToHost));
+    extra_now[1] /= (double)(h->base.n > 1 ? h->base.n - 1 : 1);
+  }
+  return PSTAT_OK;
+}
+
 // checkpoint image: header, then the ten state buffers in allocation order
 struct CkptHeader {
   uint64_t magic;
@@ -625,7 +691,7 @@ int pstat_launch_info_get(pstat_handle *h, pstat_launch_info *out) {
   int lds = 0, bpc = 0;
   const char *name = "";
   if (h->base.energy_type == PSTAT_INTERACTING) HIP_TRY(interacting_kernel_info(h->cfg, h->base.n, &bpc, &name));
-  else HIP_TRY(sweep_kernel_info(h->cfg, h->args, &lds, &bpc, &name));
+  else HIP_TRY(kernel_info(h->cfg, h->args, &lds, &bpc, &name));
   std::snprintf(out->kernel, sizeof out->kernel, "%s", name);
   out->lds_bytes = lds;
   out->threads_per_block = 64;

@@ -1,0 +1,459 @@
+// pstat_cluster.hip -- the step of mcmc_clustering_eap_chain.jl:268-311 on gfx950.
+//
+// One step of that main is ONE proposal made of two parts applied to the trial chain: the
+// single-monomer move of mcmc_eap_chain.jl (move!, inc/eap_chain.jl:232-258) and then cluster_flip!
+// (inc/eap_chain.jl:269-333): with probability 1 - cluster_prob a cluster is grown from the moved
+// monomer -- link (i, i+1) joins with probability (1 + n_i . n_{i+1}) / 2 -- and every member is
+// reflected through the plane normal to the field (theta -> pi - theta).  The proposal is accepted by
+// Metropolis-Hastings with the ratio alpha of the boundary probabilities (inc/acceptance.jl:29-39).
+// The energy also carries the bending term kappa/2 (psi - psi0)^2 of every bond (eap_chain.jl:54-58)
+// and two more observables are recorded: sum cos^2(theta) and the mean bond angle.
+//
+// Layout is the sweep kernel's: one chain per lane, angles in LDS as [monomer][lane], everything
+// else in registers, the same persistent (block, segment) job queue.  What differs is the step:
+//   * the n-hats of the two neighbours are always needed (bond angles), and the cluster growth walks
+//     outwards from idx reading one LDS row per accepted link -- a per-lane loop, so the wave runs
+//     as long as its longest cluster;
+//   * a reflection leaves every interior bond (angle, Ising pair energy) unchanged, so the energy
+//     difference of the whole proposal is the single move's O(1) difference plus two boundary bonds
+//     plus the members' field terms, which are accumulated while the cluster grows;
+//   * an accepted proposal rewrites theta of every member in LDS.
+// Reference behaviour kept on purpose: the acceptor caches log(pi) + log(alpha) of the last accepted
+// proposal (acceptance.jl:33-36), so later comparisons are offset by that log(alpha) -- `lag` below.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "pstat_device.h"
+#include "pstat_math.h"
+
+namespace pstat {
+
+namespace {
+
+template <typename R> struct V3 { R x, y, z; };
+template <typename R> __device__ __forceinline__ R dot3(const V3<R> &a, const V3<R> &b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+__device__ __forceinline__ float acos_r(float x) { return acosf(x); }
+__device__ __forceinline__ double acos_r(double x) { return acos(x); }
+__device__ __forceinline__ float log_r(float x) { return __logf(x); }
+__device__ __forceinline__ double log_r(double x) { return log(x); }
+
+// psi_j, inc/eap_chain.jl:45-47
+template <typename R> __device__ __forceinline__ R bond_angle(const V3<R> &a, const V3<R> &b) {
+  return acos_r(fmin((R)1, fmax((R)-1, dot3(a, b))));
+}
+
+template <typename R, typename G, int CT, int EN>
+__device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const DevState &S, const CaseConst &cc,
+                                                    const int umb_on, unsigned char *smem, const int lane,
+                                                    const int64_t c, int64_t step, int64_t remaining) {
+  using R2 = typename Vec2<R>::type;
+  using AG = Ang<R>;
+  using T3 = V3<R>;
+  R2 *ang = reinterpret_cast<R2 *>(smem);  // [n][lanes], (theta, phi)
+  const int lanes = A.lanes;
+  const int64_t C = S.C;
+  const int n = (int)A.n;
+
+  const R Fz = (R)cc.Fz, Fx = (R)cc.Fx, b = (R)cc.b, kT = (R)cc.kT;
+  const R a_or_mu = (CT == PSTAT_DIELECTRIC) ? (R)((cc.K1 - cc.K2) * cc.E0) : (R)cc.mu;
+  const R k2e = (R)(cc.K2 * cc.E0);
+  const R mhalfE0 = (R)(-0.5 * cc.E0);
+  const R hb = (R)(-cc.b / 2);
+  const R nbeta_log2e = (R)(-1.4426950408889634 / cc.kT);
+  const R khalf = (R)(cc.kappa / 2), psi0 = (R)cc.psi0;
+  const R cprob = (R)cc.cluster_prob;
+  (void)hb; (void)nbeta_log2e; (void)kT;
+
+  {  // ---- fill
+    const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) {
+      R2 v;
+      v.x = gth[(int64_t)i * C + c];
+      v.y = gph[(int64_t)i * C + c];
+      ang[i * lanes + lane] = v;
+    }
+  }
+  G g;
+  g.load(S.rng + c, C);
+  double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
+  R phistep = (R)(phistep_d / AG::unit), thstep = (R)(thstep_d / AG::unit);
+  int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
+  int nacc_seg = 0, steps_seg = 0;
+  R Orx = (R)S.obs[OBS_R1 * C + c], Ory = (R)S.obs[OBS_R2 * C + c], Orz = (R)S.obs[OBS_R3 * C + c];
+  R Opx = (R)S.obs[OBS_P1 * C + c], Opy = (R)S.obs[OBS_P2 * C + c], Opz = (R)S.obs[OBS_P3 * C + c];
+  R OU = (R)S.obs[OBS_U * C + c];
+  R usum = (R)S.obs[OBS_USUM * C + c];      // sum of u_i INCLUDING the bending terms (eap_chain.jl:53-58)
+  R c2sum = (R)S.obs[OBS_C2 * C + c], psisum = (R)S.obs[OBS_PSI * C + c];
+  R lag = (R)S.lag[c];                      // log(alpha) of the last accepted proposal of this mcmc() call
+  const bool umb = umb_on != 0;
+  const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
+  const R uref = umb ? (R)S.uref[c] : (R)0;
+  double wnorm = umb ? S.wnorm[c] : 0.0;
+  double sums[NSUMS];
+#pragma unroll
+  for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
+  const R inv_nm1 = n > 1 ? (R)(1.0 / (double)(n - 1)) : (R)0;
+
+  const int64_t spa = A.steps_per_adjust;
+  int64_t to_adj = A.adaptive ? spa - (step % spa) : 0;
+  constexpr int FLUSH = 128;
+  int left = (int)remaining;
+
+  // n-hat and dipole of monomer i from its stored angles
+  // (returns whether theta sits exactly on a clamp value, see `edge` below)
+  auto load_nm = [&](const int i, T3 &nh, T3 &mu) __attribute__((always_inline)) -> bool {
+    const R2 a = ang[i * lanes + lane];
+    R s, co, sp, cp;
+    AG::sc(a.x, &s, &co);
+    AG::sc(a.y, &sp, &cp);
+    nh.x = cp * s; nh.y = sp * s; nh.z = co;
+    dipole<R, CT>(a_or_mu, k2e, nh.x, nh.y, nh.z, mu.x, mu.y, mu.z);
+    return a.x == (R)0 || a.x == AG::theta_max;
+  };
+  // reflection through the plane normal to the field: refl_n!, inc/eap_chain.jl:263-265
+  auto refl_theta = [&](const R th) __attribute__((always_inline)) -> R {
+    if constexpr (sizeof(R) == 8) return fmin(AG::theta_max, fmax((R)0, th + (AG::theta_max - 2 * th)));
+    else return AG::theta_max - th;
+  };
+  auto refl_n = [](const T3 &v) __attribute__((always_inline)) -> T3 { return T3{v.x, v.y, -v.z}; };
+  auto refl_mu = [](const T3 &m) __attribute__((always_inline)) -> T3 {
+    if constexpr (CT == PSTAT_DIELECTRIC) return T3{-m.x, -m.y, m.z};   // a nz (nx, ny, nz) + k2e z
+    else return T3{m.x, m.y, -m.z};
+  };
+  // what bond (a, b) contributes: its angle, bending energy and (Ising) dipole-dipole energy
+  auto bond = [&](const T3 &na, const T3 &ma, const T3 &nb, const T3 &mb, R &psi, R &ebend, R &epair)
+      __attribute__((always_inline)) {
+    psi = bond_angle<R>(na, nb);
+    ebend = khalf * (psi - psi0) * (psi - psi0);
+    if constexpr (EN == PSTAT_ISING)
+      epair = pair_term_fast(hb * (na.x + nb.x), hb * (na.y + nb.y), hb * (na.z + nb.z),
+                             ma.x, ma.y, ma.z, mb.x, mb.y, mb.z);
+    else epair = 0;
+  };
+
+  while (left > 0) {
+    int chunk = left < FLUSH ? left : FLUSH;
+    if (A.adaptive && to_adj < chunk) chunk = (int)to_adj;
+    R a1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, a2[7] = {0, 0, 0, 0, 0, 0, 0};
+    R accw = 0;
+
+    for (int s = 0; s < chunk; ++s) {
+      // ---- the single-monomer part, mcmc_clustering_eap_chain.jl:269-272
+      const int idx = (int)__umulhi(g.next(), (uint32_t)n);
+      const uint32_t wphi = g.next(), wth = g.next();
+      const int cell = idx * lanes + lane;
+      const R2 a0 = ang[cell];
+      const R th0 = a0.x, ph0 = a0.y;
+      const R ph1 = AG::wrap(ph0 + phistep * sym11<R>(wphi));
+      const R th1 = fmin(AG::theta_max, fmax((R)0, th0 + thstep * sym11<R>(wth)));
+      R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
+      AG::sc(th0, &st0, &ct0);
+      AG::sc(th1, &st1, &ct1);
+      AG::sc(ph0, &sp0, &cp0);
+      AG::sc(ph1, &sp1, &cp1);
+      const T3 n0{cp0 * st0, sp0 * st0, ct0}, n1{cp1 * st1, sp1 * st1, ct1};
+      T3 m0, m1;
+      dipole<R, CT>(a_or_mu, k2e, n0.x, n0.y, n0.z, m0.x, m0.y, m0.z);
+      dipole<R, CT>(a_or_mu, k2e, n1.x, n1.y, n1.z, m1.x, m1.y, m1.z);
+      const bool hasL = idx > 0, hasR = idx + 1 < n;
+      T3 nL{0, 0, 1}, mL{0, 0, 0}, nR{0, 0, 1}, mR{0, 0, 0};
+      bool edgeL = false, edgeR = false;
+      if (hasL) edgeL = load_nm(idx - 1, nL, mL);
+      if (hasR) edgeR = load_nm(idx + 1, nR, mR);
+      const R du_field = mhalfE0 * (m1.z - m0.z);
+      R dpsi = 0, dbend = 0, dpair = 0;
+      if (hasL) {
+        R p0, e0, q0, p1, e1, q1;
+        bond(nL, mL, n0, m0, p0, e0, q0);
+        bond(nL, mL, n1, m1, p1, e1, q1);
+        dpsi += p1 - p0; dbend += e1 - e0; dpair += q1 - q0;
+      }
+      if (hasR) {
+        R p0, e0, q0, p1, e1, q1;
+        bond(n0, m0, nR, mR, p0, e0, q0);
+        bond(n1, m1, nR, mR, p1, e1, q1);
+        dpsi += p1 - p0; dbend += e1 - e0; dpair += q1 - q0;
+      }
+
+      // ---- cluster_flip!(trial, idx), inc/eap_chain.jl:269-333
+      // `edge`: a member's theta is exactly 0 or pi (only a clamp produces those).  The reference
+      // re-derives sin(theta) after the reflection and fl(pi) -> 0 turns 1.2e-16 into an exact 0, so
+      // its log-density of such a proposal is -inf (or NaN): never accepted.
+      R alpha = 1;
+      bool flipped = false, edge = false;
+      int upper = idx, lower = idx;
+      R drz_flip = 0, du_flip = 0, dpair_flip = 0, dpsi_flip = 0;
+      T3 dp_flip{0, 0, 0};
+      if (!(u01<R>(g.next()) <= cprob)) {                                   // :276
+        flipped = true;
+        edge = th1 == (R)0 || th1 == AG::theta_max;
+        R snz = n1.z;                 // sums over the members (the moved monomer enters as proposed)
+        T3 sm = m1;
+        R upper_p, lower_p, new_upper_p = 0, new_lower_p = 0;
+        {  // grow towards the chain end, :281-292
+          T3 cur = n1, curm = m1, nxt = nR, nxtm = mR;
+          bool nxt_edge = edgeR;
+          for (;;) {
+            if (upper >= n - 1) { upper_p = 0; break; }
+            upper_p = (1 + dot3(cur, nxt)) / 2;
+            if (!(u01<R>(g.next()) <= upper_p)) break;
+            ++upper;
+            cur = nxt; curm = nxtm;
+            edge = edge || nxt_edge;
+            snz += cur.z; sm.x += curm.x; sm.y += curm.y; sm.z += curm.z;
+            if (upper < n - 1) nxt_edge = load_nm(upper + 1, nxt, nxtm);
+          }
+          if (upper < n - 1) {  // boundary bond (upper, upper+1) before and after the reflection, :318-321
+            const T3 rf = refl_n(cur), rfm = refl_mu(curm);
+            R p0, e0, q0, p1, e1, q1;
+            bond(cur, curm, nxt, nxtm, p0, e0, q0);
+            bond(rf, rfm, nxt, nxtm, p1, e1, q1);
+            new_upper_p = (1 + dot3(rf, nxt)) / 2;
+            dpsi_flip += p1 - p0; du_flip += e1 - e0; dpair_flip += q1 - q0;
+          }
+        }
+        {  // grow towards the chain start, :298-309
+          T3 cur = n1, curm = m1, nxt = nL, nxtm = mL;
+          bool nxt_edge = edgeL;
+          for (;;) {
+            if (lower <= 0) { lower_p = 0; break; }
+            lower_p = (1 + dot3(cur, nxt)) / 2;
+            if (!(u01<R>(g.next()) <= lower_p)) break;
+            --lower;
+            cur = nxt; curm = nxtm;
+            edge = edge || nxt_edge;
+            snz += cur.z; sm.x += curm.x; sm.y += curm.y; sm.z += curm.z;
+            if (lower > 0) nxt_edge = load_nm(lower - 1, nxt, nxtm);
+          }
+          if (lower > 0) {      // boundary bond (lower-1, lower), :323-326
+            const T3 rf = refl_n(cur), rfm = refl_mu(curm);
+            R p0, e0, q0, p1, e1, q1;
+            bond(nxt, nxtm, cur, curm, p0, e0, q0);
+            bond(nxt, nxtm, rf, rfm, p1, e1, q1);
+            new_lower_p = (1 + dot3(rf, nxt)) / 2;
+            dpsi_flip += p1 - p0; du_flip += e1 - e0; dpair_flip += q1 - q0;
+          }
+        }
+        alpha = ((1 - new_upper_p) * (1 - new_lower_p)) / ((1 - upper_p) * (1 - lower_p));   // :328-329
+        // members' own terms: n_z -> -n_z; dielectric mu -> (-mu_x, -mu_y, mu_z), polar mu_z -> -mu_z
+        drz_flip = b * (-2 * snz);
+        if constexpr (CT == PSTAT_DIELECTRIC) { dp_flip.x = -2 * sm.x; dp_flip.y = -2 * sm.y; }
+        else { dp_flip.z = -2 * sm.z; du_flip += mhalfE0 * dp_flip.z; }
+      }
+      const uint32_t weps = g.next();   // the acceptance draw comes after the cluster's draws
+
+      // ---- energy difference of the whole proposal, inc/energy.jl:7-23
+      const R drx = b * (n1.x - n0.x), dry = b * (n1.y - n0.y), drz = b * (n1.z - n0.z) + drz_flip;
+      const R dus = du_field + dbend + du_flip;        // change of sum(u), bending included
+      const R dU = dus + (dpair + dpair_flip) - (Fx * drx + Fz * drz);
+
+      // ---- Metropolis-Hastings, inc/acceptance.jl:29-39
+      bool ok;
+      const R dw = umb ? dus * wscale : (R)0;
+      if constexpr (sizeof(R) == 8) {
+        const R delta = -dU / kT + log(st1 / st0) + dw + log(alpha) - lag;
+        const R eps = u01<R>(weps);
+        ok = (delta >= 0) || (eps < exp(delta));
+      } else {
+        const R e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lag) + dU * nbeta_log2e) * alpha;
+        ok = bits12(weps) * st0 < fma_r(st1, e, st0);   // (1 + u) sin0 < sin1 e alpha + sin0
+      }
+
+      ok = ok && !edge;
+
+      // ---- commit
+      if (ok) {
+        R2 a1;
+        a1.x = flipped ? refl_theta(th1) : th1;
+        a1.y = ph1;
+        ang[cell] = a1;
+        if (flipped) {
+          for (int i = lower; i <= upper; ++i) {
+            if (i == idx) continue;
+            R2 v = ang[i * lanes + lane];
+            v.x = refl_theta(v.x);
+            ang[i * lanes + lane] = v;
+          }
+        }
+        Orx += drx; Ory += dry; Orz += drz;
+        Opx += (m1.x - m0.x) + dp_flip.x; Opy += (m1.y - m0.y) + dp_flip.y; Opz += (m1.z - m0.z) + dp_flip.z;
+        OU += dU;
+        usum += dus;
+        psisum += dpsi + dpsi_flip;
+        c2sum += ct1 * ct1 - ct0 * ct0;
+        lag = log_r(alpha);
+        ++nacc_seg;
+      }
+
+      // ---- record! x 10, mcmc_clustering_eap_chain.jl:243-244,310-311
+      const R wgt = umb ? exp_r(-(usum - uref) * wscale) : (R)1;
+      const R psim = psisum * inv_nm1;
+      accw += wgt;
+      a1[0] = fma_r(wgt, Orx, a1[0]); a1[1] = fma_r(wgt, Ory, a1[1]); a1[2] = fma_r(wgt, Orz, a1[2]);
+      a1[3] = fma_r(wgt, Opx, a1[3]); a1[4] = fma_r(wgt, Opy, a1[4]); a1[5] = fma_r(wgt, Opz, a1[5]);
+      a1[6] = fma_r(wgt, OU, a1[6]); a1[7] = fma_r(wgt, c2sum, a1[7]); a1[8] = fma_r(wgt, psim, a1[8]);
+      a2[0] = fma_r(wgt * Orx, Orx, a2[0]); a2[1] = fma_r(wgt * Ory, Ory, a2[1]); a2[2] = fma_r(wgt * Orz, Orz, a2[2]);
+      a2[3] = fma_r(wgt * Opx, Opx, a2[3]); a2[4] = fma_r(wgt * Opy, Opy, a2[4]); a2[5] = fma_r(wgt * Opz, Opz, a2[5]);
+      a2[6] = fma_r(wgt * OU, OU, a2[6]);
+    }
+
+    sums[S_R1] += (double)a1[0]; sums[S_R2] += (double)a1[1]; sums[S_R3] += (double)a1[2];
+    sums[S_P1] += (double)a1[3]; sums[S_P2] += (double)a1[4]; sums[S_P3] += (double)a1[5];
+    sums[S_U] += (double)a1[6]; sums[S_C2] += (double)a1[7]; sums[S_PSI] += (double)a1[8];
+    sums[S_R1SQ] += (double)a2[0]; sums[S_R2SQ] += (double)a2[1]; sums[S_R3SQ] += (double)a2[2];
+    sums[S_P1SQ] += (double)a2[3]; sums[S_P2SQ] += (double)a2[4]; sums[S_P3SQ] += (double)a2[5];
+    sums[S_USQ] += (double)a2[6];
+    wnorm += (double)accw;
+    step += chunk;
+    left -= chunk;
+    steps_seg += chunk;
+
+    // ---- step-size adaptation, mcmc_clustering_eap_chain.jl:287-308
+    if (A.adaptive) {
+      to_adj -= chunk;
+      if (to_adj == 0) {
+        to_adj = spa;
+        const int nacc = nacc_off + nacc_seg, natt = natt_off + steps_seg;
+        const double ratio = (double)nacc / (double)natt;
+        if (ratio > A.adj_ub && phistep_d != K<double>::pi && thstep_d != K<double>::half_pi) {
+          nacc_off = -nacc_seg; natt_off = -steps_seg;
+          phistep_d = fmin(K<double>::pi, phistep_d * A.adj_scale);
+          thstep_d = fmin(K<double>::half_pi, thstep_d * A.adj_scale);
+        } else if (ratio < A.adj_lb) {
+          nacc_off = -nacc_seg; natt_off = -steps_seg;
+          phistep_d /= A.adj_scale;
+          thstep_d /= A.adj_scale;
+        }
+        phistep = (R)(phistep_d / AG::unit); thstep = (R)(thstep_d / AG::unit);
+      }
+    }
+  }
+
+  {  // ---- spill
+    R *gth = (R *)S.ang, *gph = (R *)S.ang + (int64_t)n * C;
+    for (int i = 0; i < n; ++i) {
+      const R2 v = ang[i * lanes + lane];
+      gth[(int64_t)i * C + c] = v.x;
+      gph[(int64_t)i * C + c] = v.y;
+    }
+  }
+  g.store(S.rng + c, C);
+  S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
+  S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
+  S.nacc_total[c] += nacc_seg;
+  S.obs[OBS_R1 * C + c] = Orx; S.obs[OBS_R2 * C + c] = Ory; S.obs[OBS_R3 * C + c] = Orz;
+  S.obs[OBS_P1 * C + c] = Opx; S.obs[OBS_P2 * C + c] = Opy; S.obs[OBS_P3 * C + c] = Opz;
+  S.obs[OBS_U * C + c] = OU; S.obs[OBS_USUM * C + c] = usum;
+  S.obs[OBS_C2 * C + c] = c2sum; S.obs[OBS_PSI * C + c] = psisum;
+  S.lag[c] = lag;
+  if (umb) S.wnorm[c] = wnorm;
+#pragma unroll
+  for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
+}
+
+// the sweep kernel's persistent job loop (pstat_kernels.hip) around run_cluster_segment
+template <typename R, typename G, int CT, int EN>
+__global__ __launch_bounds__(64) void cluster_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
+                                                     int umbrella, int *__restrict__ queue) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int nblocks = (int)(A.blocks_per_case * A.ncases);
+  const int njobs = nblocks * A.nseg;
+  int *head = queue, *error = queue + 1, *done = queue + 2;
+  bool failed = false;
+  while (!failed) {
+    int job = 0;
+    if (lane == 0) job = atomicAdd(head, 1);
+    job = __builtin_amdgcn_readfirstlane(job);
+    if (job >= njobs) break;
+    const int blk = job % nblocks, seg = job / nblocks;
+    if (seg > 0) {
+      int spins = 0;
+      for (;;) {
+        const int have = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load(&done[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (have >= seg) break;
+        if (++spins > A.max_spins) { failed = true; break; }
+        __builtin_amdgcn_s_sleep(64);
+      }
+      if (failed) {
+        if (lane == 0) atomicExch(error, 1 + job);
+        break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    const int64_t icase = blk / A.blocks_per_case;
+    const int64_t local = (int64_t)(blk % A.blocks_per_case) * A.lanes + lane;
+    const int64_t first = (int64_t)seg * A.seg_len;
+    const int64_t rest = A.nsteps - first;
+    const int64_t len = rest < A.seg_len ? rest : A.seg_len;
+    if (len > 0 && lane < A.lanes && local < A.chains_per_case) {
+      const CaseConst cc = cases[icase];
+      run_cluster_segment<R, G, CT, EN>(A, S, cc, umbrella, smem, lane, icase * A.chains_per_case + local,
+                                        A.step0 + first, len);
+    }
+    if (A.nseg > 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&done[blk], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+using ClusterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int *);
+
+template <typename R, typename G>
+ClusterFn pick_ct_en(const LaunchCfg &cfg) {
+  const bool ising = cfg.energy_type == PSTAT_ISING;
+  if (cfg.chain_type == PSTAT_DIELECTRIC)
+    return ising ? cluster_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_ISING>
+                 : cluster_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING>;
+  return ising ? cluster_kernel<R, G, PSTAT_POLAR, PSTAT_ISING>
+               : cluster_kernel<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING>;
+}
+
+ClusterFn pick_cluster(const LaunchCfg &cfg) {
+  if (cfg.precision == PSTAT_F64)
+    return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_ct_en<double, Xoshiro128pp>(cfg) : pick_ct_en<double, Mwc64x>(cfg);
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_ct_en<float, Xoshiro128pp>(cfg) : pick_ct_en<float, Mwc64x>(cfg);
+}
+
+int cluster_lds_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
+  return (int)(a.n * a.lanes * (cfg.precision == PSTAT_F64 ? 16 : 8));
+}
+
+}  // namespace
+
+hipError_t cluster_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes, int *blocks_per_cu,
+                               const char **name) {
+  ClusterFn fn = pick_cluster(cfg);
+  const int lds = cluster_lds_bytes(cfg, a);
+  hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  int nb = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fn, 64, lds);
+  if (e != hipSuccess) return e;
+  if (lds_bytes) *lds_bytes = lds;
+  if (blocks_per_cu) *blocks_per_cu = nb;
+  if (name) *name = cfg.precision == PSTAT_F64 ? "cluster_kernel<double>" : "cluster_kernel<float>";
+  return hipSuccess;
+}
+
+hipError_t launch_cluster(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s, const CaseConst *cases,
+                          int *queue, unsigned grid, hipStream_t stream) {
+  ClusterFn fn = pick_cluster(cfg);
+  const int lds = cluster_lds_bytes(cfg, a);
+  hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(queue, 0, sizeof(int) * sweep_queue_ints(a), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a, s, cases, cfg.umbrella, queue);
+  return hipGetLastError();
+}
+
+}  // namespace pstat

@@ -13,10 +13,14 @@ namespace pstat {
 // consecutive elements: every spill/fill of chain state is a fully coalesced 256/512-byte access.
 // C = ncases * chains_per_case.
 // ---------------------------------------------------------------------------------------------
-enum { OBS_R1 = 0, OBS_R2, OBS_R3, OBS_P1, OBS_P2, OBS_P3, OBS_U, OBS_USUM, NOBS_STATE };
-// per-chain running sums kept on the device; r.r and p.p are the sums of their components
+enum { OBS_R1 = 0, OBS_R2, OBS_R3, OBS_P1, OBS_P2, OBS_P3, OBS_U, OBS_USUM,
+       OBS_C2,    // sum_i cos^2(theta_i)            (clustering main, mcmc_clustering_eap_chain.jl:243)
+       OBS_PSI,   // sum of the n-1 bond angles psi   (:244)
+       NOBS_STATE };
+// per-chain running sums kept on the device; r.r and p.p are the sums of their components.  The
+// first NSUMS_BASE are what mcmc_eap_chain.jl records; the clustering main adds two more.
 enum { S_R1 = 0, S_R2, S_R3, S_R1SQ, S_R2SQ, S_R3SQ, S_P1, S_P2, S_P3, S_P1SQ, S_P2SQ, S_P3SQ,
-       S_U, S_USQ, NSUMS };
+       S_U, S_USQ, NSUMS_BASE, S_C2 = NSUMS_BASE, S_PSI, NSUMS };
 
 struct DevState {
   void *ang;            // R  [2][n][C]   plane 0 = theta, plane 1 = phi (radians)
@@ -38,6 +42,13 @@ struct DevState {
 struct CaseConst {      // physics scalars of one case (inc/eap_chain.jl:89-108)
   double E0, K1, K2, mu, kT, Fz, Fx, b;
   uint64_t seed, chain_id0;
+  double kappa, psi0;     // --bend-mod, --bend-angle (clustering main; 0 in mcmc_eap_chain.jl)
+  double cluster_prob;    // --cluster-prob: probability of NOT attempting a cluster flip
+};
+
+struct InitOpts {       // how EAPChain(pargs) draws the first configuration (inc/eap_chain.jl:61-72)
+  int use_x0;
+  double x0_phi, x0_theta, dx0_phi, dx0_theta;
 };
 
 struct SweepArgs {
@@ -167,10 +178,17 @@ struct LaunchCfg {
   int precision, chain_type, energy_type, do_flips, umbrella, has_fx;
   int lag;  // a re-init has happened on this handle
   int rng;  // PSTAT_RNG_MWC64X | PSTAT_RNG_XOSHIRO128PP
+  int move_set;  // PSTAT_MOVES_SINGLE (mcmc_eap_chain.jl) | PSTAT_MOVES_CLUSTER (mcmc_clustering_eap_chain.jl)
 };
 hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                        const CaseConst *cases, double phi_step, double theta_step,
-                       hipStream_t stream);
+                       const InitOpts &io, hipStream_t stream);
+hipError_t launch_reset_sampler(const DevState &s, double phi_step, double theta_step, hipStream_t stream);
+// clustering main (pstat_cluster.hip): single-monomer move + cluster_flip! per step
+hipError_t launch_cluster(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
+                          const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream);
+hipError_t cluster_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
+                               int *blocks_per_cu, const char **name);
 hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                         const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream);
 size_t sweep_queue_ints(const SweepArgs &a);

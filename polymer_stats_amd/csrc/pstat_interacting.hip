@@ -140,9 +140,9 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
   const R uref = umb ? (R)S.uref[c] : (R)0;
   double wnorm = umb ? S.wnorm[c] : 0.0;
-  double sums[NSUMS];
+  double sums[NSUMS_BASE];
 #pragma unroll
-  for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
+  for (int q = 0; q < NSUMS_BASE; ++q) sums[q] = S.sums[q * C + c];
 
   // ---- derive my monomers and the chain totals (inc/eap_chain.jl:109-134)
   R st[M], nx[M], ny[M], nz[M], mx[M], my[M], mz[M], xx[M], xy[M], xz[M];
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
     S.obs[OBS_U * C + c] = U; S.obs[OBS_USUM * C + c] = usum;
     S.lag[c] = lag;
     if (umb) S.wnorm[c] = wnorm;
-    for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
+    for (int q = 0; q < NSUMS_BASE; ++q) S.sums[q * C + c] = sums[q];
   }
 }
 

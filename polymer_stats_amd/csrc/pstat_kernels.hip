@@ -41,7 +41,8 @@ namespace pstat {
 // One thread per chain; angles are rounded to the storage type R before anything is derived.
 template <typename R, typename G>
 __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
-                            int chain_type, int energy_type, double phi_step, double theta_step) {
+                            int chain_type, int energy_type, double phi_step, double theta_step,
+                            InitOpts io) {
   int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= S.C) return;
   const int64_t icase = c / A.chains_per_case, local = c % A.chains_per_case;
@@ -49,10 +50,17 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
   R *th = (R *)S.ang, *ph = (R *)S.ang + A.n * S.C;
   G g;
   g.seed(cc.seed, cc.chain_id0 + (uint64_t)local);
-  for (int64_t i = 0; i < A.n; ++i) ph[i * S.C + c] = store_phi<R>(u01<double>(g.next()));
-  for (int64_t i = 0; i < A.n; ++i) th[i * S.C + c] = store_theta<R>(u01<double>(g.next()));
+  if (io.use_x0) {  // x0 = [phi; theta] plus Uniform(0, dx0), inc/eap_chain.jl:69-72
+    for (int64_t i = 0; i < A.n; ++i)
+      ph[i * S.C + c] = store_phi_rad<R>(io.x0_phi + io.dx0_phi * u01<double>(g.next()));
+    for (int64_t i = 0; i < A.n; ++i)
+      th[i * S.C + c] = store_theta_rad<R>(io.x0_theta + io.dx0_theta * u01<double>(g.next()));
+  } else {
+    for (int64_t i = 0; i < A.n; ++i) ph[i * S.C + c] = store_phi<R>(u01<double>(g.next()));
+    for (int64_t i = 0; i < A.n; ++i) th[i * S.C + c] = store_theta<R>(u01<double>(g.next()));
+  }
 
-  double r[3] = {0, 0, 0}, p[3] = {0, 0, 0}, usum = 0, upair = 0, omega = 0;
+  double r[3] = {0, 0, 0}, p[3] = {0, 0, 0}, usum = 0, upair = 0, omega = 0, c2sum = 0, psisum = 0;
   double pnx = 0, pny = 0, pnz = 0, pmx = 0, pmy = 0, pmz = 0;
   for (int64_t i = 0; i < A.n; ++i) {
     double t = load_theta<R>(th[i * S.C + c]), f = load_phi<R>(ph[i * S.C + c]);
@@ -66,6 +74,12 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
     p[0] += mx; p[1] += my; p[2] += mz;
     usum += -0.5 * cc.E0 * mz;
     omega += log(st);
+    c2sum += ct * ct;
+    if (i > 0) {  // bond (i-1, i): angle psi and its bending energy, inc/eap_chain.jl:45-47,54-58
+      const double psi = acos(fmin(1.0, fmax(-1.0, pnx * nx + pny * ny + pnz * nz)));
+      psisum += psi;
+      usum += cc.kappa / 2 * (psi - cc.psi0) * (psi - cc.psi0);
+    }
     if (energy_type == PSTAT_ISING && i > 0) {
       double h = -cc.b / 2;
       upair += pair_term<double>(h * (pnx + nx), h * (pny + ny), h * (pnz + nz), pmx, pmy, pmz, mx, my, mz);
@@ -76,6 +90,7 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
   S.obs[OBS_R1 * S.C + c] = r[0]; S.obs[OBS_R2 * S.C + c] = r[1]; S.obs[OBS_R3 * S.C + c] = r[2];
   S.obs[OBS_P1 * S.C + c] = p[0]; S.obs[OBS_P2 * S.C + c] = p[1]; S.obs[OBS_P3 * S.C + c] = p[2];
   S.obs[OBS_U * S.C + c] = U; S.obs[OBS_USUM * S.C + c] = usum;
+  S.obs[OBS_C2 * S.C + c] = c2sum; S.obs[OBS_PSI * S.C + c] = psisum;
   g.store(S.rng + c, S.C);
   S.stepsz[0 * S.C + c] = phi_step; S.stepsz[1 * S.C + c] = theta_step;
   S.win[0 * S.C + c] = 0; S.win[1 * S.C + c] = 0;
@@ -181,9 +196,9 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
   const R uref = umb ? (R)S.uref[c] : (R)0;
   double wnorm = umb ? S.wnorm[c] : 0.0;
-  double sums[NSUMS];
+  double sums[NSUMS_BASE];
 #pragma unroll
-  for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
+  for (int q = 0; q < NSUMS_BASE; ++q) sums[q] = S.sums[q * C + c];
 
   const int64_t spa = A.steps_per_adjust;
   int64_t to_adj = A.adaptive ? spa - (step % spa) : 0;
@@ -463,7 +478,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     if (umb) S.wnorm[c] = wnorm;
   }
 #pragma unroll
-  for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
+  for (int q = 0; q < NSUMS_BASE; ++q) S.sums[q * C + c] = sums[q];
 }
 
 // Persistent sweep kernel.  A job = (chain block, time segment); jobs are handed out in segment-major
@@ -531,7 +546,7 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
 
 constexpr int RED_BLOCKS = 256;
 constexpr int RED_THREADS = 256;
-constexpr int NQ = 17;  // 16 observables + acceptance ratio
+constexpr int NQ = 19;  // 16 observables + acceptance ratio + the clustering main's two extras
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -565,6 +580,8 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_stage1(DevState S, int64_t
 #pragma unroll
     for (int q = 0; q < PSTAT_NOBS; ++q) v[q] *= inv;
     v[16] = steps > 0 ? (double)S.nacc_total[c] / (double)steps : 0.0;
+    v[17] = S.sums[S_C2 * C + c] * inv;    // sum cos^2(theta)
+    v[18] = S.sums[S_PSI * C + c] * inv;   // mean bond angle
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { m1[q] += v[q]; m2[q] = fma(v[q], v[q], m2[q]); }
   }
@@ -597,6 +614,18 @@ __global__ __launch_bounds__(64) void reduce_stage2(const double *__restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------ re-init
+
+// What a fresh mcmc(nsteps, pargs, chain) call starts from (mcmc_clustering_eap_chain.jl:172-181):
+// default step sizes, zeroed adaptation window, an acceptor with no history, a weight function
+// gauged on the current chain.  The averagers are reset separately (pstat_reset_averages).
+__global__ void reset_sampler_kernel(DevState S, double phi_step, double theta_step) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= S.C) return;
+  S.stepsz[0 * S.C + c] = phi_step; S.stepsz[1 * S.C + c] = theta_step;
+  S.win[0 * S.C + c] = 0; S.win[1 * S.C + c] = 0;
+  S.lag[c] = 0.0;
+  S.uref[c] = S.obs[OBS_USUM * S.C + c];
+}
 
 // mcmc_eap_chain.jl:352-361: draw a fresh configuration; adopt it if forced or by
 // metropolis_acc (inc/acceptance.jl:1-3).  One thread per chain.  The reference's acceptor keeps
@@ -759,24 +788,30 @@ hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState
 
 template <typename G>
 static void launch_init_g(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s, const CaseConst *cases,
-                          double phi_step, double theta_step, unsigned grid, hipStream_t stream) {
+                          double phi_step, double theta_step, const InitOpts &io, unsigned grid, hipStream_t stream) {
   if (cfg.precision == PSTAT_F64)
     hipLaunchKernelGGL((init_kernel<double, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
-                       cfg.chain_type, cfg.energy_type, phi_step, theta_step);
+                       cfg.chain_type, cfg.energy_type, phi_step, theta_step, io);
   else if (cfg.precision == PSTAT_Q16)
     hipLaunchKernelGGL((init_kernel<uint16_t, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
-                       cfg.chain_type, cfg.energy_type, phi_step, theta_step);
+                       cfg.chain_type, cfg.energy_type, phi_step, theta_step, io);
   else
     hipLaunchKernelGGL((init_kernel<float, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
-                       cfg.chain_type, cfg.energy_type, phi_step, theta_step);
+                       cfg.chain_type, cfg.energy_type, phi_step, theta_step, io);
+}
+
+hipError_t launch_reset_sampler(const DevState &s, double phi_step, double theta_step, hipStream_t stream) {
+  hipLaunchKernelGGL(reset_sampler_kernel, dim3((unsigned)((s.C + 255) / 256)), dim3(256), 0, stream, s,
+                     phi_step, theta_step);
+  return hipGetLastError();
 }
 
 hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                        const CaseConst *cases, double phi_step, double theta_step,
-                       hipStream_t stream) {
+                       const InitOpts &io, hipStream_t stream) {
   const unsigned grid = (unsigned)((s.C + 255) / 256);
-  if (cfg.rng == PSTAT_RNG_XOSHIRO128PP) launch_init_g<Xoshiro128pp>(cfg, a, s, cases, phi_step, theta_step, grid, stream);
-  else launch_init_g<Mwc64x>(cfg, a, s, cases, phi_step, theta_step, grid, stream);
+  if (cfg.rng == PSTAT_RNG_XOSHIRO128PP) launch_init_g<Xoshiro128pp>(cfg, a, s, cases, phi_step, theta_step, io, grid, stream);
+  else launch_init_g<Mwc64x>(cfg, a, s, cases, phi_step, theta_step, io, grid, stream);
   return hipGetLastError();
 }
 

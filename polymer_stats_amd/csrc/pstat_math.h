@@ -100,6 +100,19 @@ template <typename T> __device__ __forceinline__ T store_theta(double u) { // th
   else if constexpr (sizeof(T) == 4) return (T)(0.5 * u);
   else return (T)(3.14159265358979323846 * u);
 }
+// an arbitrary angle in radians -> storage (the x0 start; f32/q16 keep phi mod 2 pi, theta as given)
+template <typename T> __device__ __forceinline__ T store_phi_rad(double phi) {
+  if constexpr (sizeof(T) == 8) return (T)phi;
+  double t = phi / 6.28318530717958647692;
+  t -= floor(t);
+  if constexpr (sizeof(T) == 2) return (T)(uint32_t)fmin(65535.0, t * 65536.0);
+  else return (T)t;
+}
+template <typename T> __device__ __forceinline__ T store_theta_rad(double theta) {
+  if constexpr (sizeof(T) == 8) return (T)theta;
+  else if constexpr (sizeof(T) == 2) return (T)(uint32_t)fmin(65535.0, fmax(0.0, theta / 3.14159265358979323846 * 65536.0));
+  else return (T)(theta / 6.28318530717958647692);
+}
 template <typename T> __host__ __device__ inline double load_phi(T raw) {     // -> radians
   if constexpr (sizeof(T) == 2) return 6.28318530717958647692 * ((double)raw + 0.5) / 65536.0;
   else if constexpr (sizeof(T) == 4) return 6.28318530717958647692 * (double)raw;

@@ -58,6 +58,11 @@ class Ensemble:
         """Discard what has been recorded so far (burn-in); chains, generators, step sizes stay."""
         check(self._L.pstat_reset_averages(self._h))
 
+    def reset_sampler(self):
+        """What a fresh mcmc(nsteps, pargs, chain) call of the reference resets besides the averagers:
+        step sizes, adaptation window, the acceptor's cache, the in-run step counter."""
+        check(self._L.pstat_reset_sampler(self._h))
+
     def set_kT(self, kT: float, icase: int = -1):
         check(self._L.pstat_set_kT(self._h, icase, float(kT)))
 
@@ -101,6 +106,14 @@ class Ensemble:
         return dict(theta=ang[:self.n], phi=ang[self.n:], sums=sums, nacc_total=int(cnt[0]),
                     steps_recorded=int(cnt[1]), nacc_window=int(cnt[2]), natt_window=int(cnt[3]),
                     phi_step=steps[0], theta_step=steps[1], normalizer=steps[2], rng=rng)
+
+    def chain_extras(self, chain: int) -> dict:
+        """Clustering main only: running sums and current values of sum cos^2(theta) and <psi>."""
+        sums = np.zeros(2)
+        now = np.zeros(2)
+        dp = C.POINTER(C.c_double)
+        check(self._L.pstat_chain_extras(self._h, chain, sums.ctypes.data_as(dp), now.ctypes.data_as(dp)))
+        return dict(sums=sums, now=now)
 
     def checkpoint(self) -> bytes:
         size = C.c_size_t(0)

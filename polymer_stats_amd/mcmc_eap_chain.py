@@ -149,7 +149,8 @@ class _Pool:
     """Chains sharded over one or more devices in this process; reductions merged on the host
     (every entry of the reduction vector is additive)."""
 
-    def __init__(self, pargs: dict):
+    def __init__(self, pargs: dict, factory=None):
+        factory = factory or params_from_pargs
         devices = [int(d) for d in str(pargs["devices"]).split(",") if d != ""]
         total = int(pargs["num-chains"])
         if total < 1:
@@ -160,7 +161,7 @@ class _Pool:
         first = 0
         for i, dev in enumerate(devices):
             cnt = base + (1 if i < extra else 0)
-            self.parts.append(Ensemble(params_from_pargs(pargs, cnt, first, dev)))
+            self.parts.append(Ensemble(factory(pargs, cnt, first, dev)))
             first += cnt
         self.steps = 0
 
@@ -184,6 +185,18 @@ class _Pool:
             e.set_kT(kT)
             e.reset_averages()
         self.steps = 0
+
+    def stage(self, kT):
+        """Start of a fresh mcmc(nsteps, pargs, chain) call of the clustering main: new temperature,
+        default step sizes, empty acceptor cache and averagers (mcmc_clustering_eap_chain.jl:172-181)."""
+        for e in self.parts:
+            e.set_kT(kT)
+            e.reset_sampler()
+            e.reset_averages()
+        self.steps = 0
+
+    def chain0(self):
+        return self.parts[0].chain_state(0)
 
     def summary(self):
         red = np.zeros(_lib.NRED)

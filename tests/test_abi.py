@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(ps):
     for n in names:
         assert hasattr(lib, n), f"libpstat.so does not export {n}"
     assert sorted(ps._lib.SYMBOLS) == names, "binding's symbol list is out of date"
-    assert lib.pstat_abi_version() == 2
+    assert lib.pstat_abi_version() == 3
 
 
 def test_struct_layout_matches_header(ps, tmp_path):
@@ -38,13 +38,16 @@ def test_struct_layout_matches_header(ps, tmp_path):
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pstat.h"\n'
                    'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(pstat_params), offsetof(pstat_params, steps_per_adjust),'
                    'offsetof(pstat_params, seed), offsetof(pstat_params, rng), sizeof(pstat_summary),'
-                   'offsetof(pstat_summary, num_chains), sizeof(pstat_launch_info));return 0;}\n')
+                   'offsetof(pstat_summary, num_chains), sizeof(pstat_launch_info));'
+                   'printf("%zu %zu %zu %zu\\n", offsetof(pstat_params, move_set), offsetof(pstat_params, bend_mod),'
+                   'offsetof(pstat_params, use_x0), offsetof(pstat_summary, extra_avg));return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     P, S, LI = ps._lib.Params, ps._lib.Summary, ps._lib.LaunchInfo
     assert got == [C.sizeof(P), P.steps_per_adjust.offset, P.seed.offset, P.rng.offset, C.sizeof(S),
-                   S.num_chains.offset, C.sizeof(LI)]
+                   S.num_chains.offset, C.sizeof(LI), P.move_set.offset, P.bend_mod.offset, P.use_x0.offset,
+                   S.extra_avg.offset]
 
 
 def test_defaults_are_the_references(ps):
@@ -56,6 +59,9 @@ def test_defaults_are_the_references(ps):
     assert (p.adj_lb, p.adj_ub, p.adj_scale, p.steps_per_adjust) == (0.15, 0.55, 1.1, 2500)
     assert p.n == 100 and p.chain_type == ps.DIELECTRIC and p.energy_type == ps.NONINTERACTING
     assert p.rng == ps.RNG_MWC64X and p.precision == ps.F32 and p.reserved == 0
+    # mcmc_clustering_eap_chain.jl:36-43,87-90,146-148
+    assert p.move_set == ps.MOVES_SINGLE and (p.bend_mod, p.bend_angle, p.cluster_prob) == (0.0, 0.0, 0.5)
+    assert p.use_x0 == 0 and (p.dx0_phi, p.dx0_theta) == (2 * math.pi, 0.1)
 
 
 def test_strerror_and_invalid_arguments(ps):
@@ -64,7 +70,9 @@ def test_strerror_and_invalid_arguments(ps):
     assert b"device" in lib.pstat_strerror(-2)
     h = C.c_void_p()
     for bad in (dict(n=0), dict(kT=-1.0), dict(chain_type=7), dict(energy_type=9), dict(num_chains=0),
-                dict(precision=5), dict(phi_step=0.0), dict(rng=3), dict(reserved=1)):
+                dict(precision=5), dict(phi_step=0.0), dict(rng=3), dict(reserved=1), dict(move_set=2),
+                dict(move_set=1, cluster_prob=1.5), dict(move_set=1, do_flips=1), dict(bend_mod=1.0),
+                dict(use_x0=1, x0_theta=float("nan"))):
         p = ps.default_params(**bad)
         rc = lib.pstat_create(C.byref(p), 1, None, C.byref(h))
         assert rc == -1, (bad, rc)

@@ -18,7 +18,8 @@ NCHAINS, NSTEPS = 24, 3000
 
 
 def reduction_vector(sums, norm, nacc, steps):
-    m = np.concatenate([sums / norm[:, None], (nacc / steps)[:, None]], axis=1)
+    # 16 observables, acceptance ratio, and the clustering main's two extras (zero in this main)
+    m = np.concatenate([sums / norm[:, None], (nacc / steps)[:, None], np.zeros((len(norm), 2))], axis=1)
     return np.concatenate([[m.shape[0]], m.sum(0), (m ** 2).sum(0)])
 
 

@@ -1,0 +1,181 @@
+"""GPU parity tests of the clustering main's step (mcmc_clustering_eap_chain.jl:268-311) -- run with -m gpu.
+
+The checker is oracle.eap_run_cluster, a literal restatement of that main (trial chain = deep copy,
+move!, cluster_flip!, full energy recomputation, acceptor caching log(pi) + log(alpha)).  The reference
+holds no fixture for this path either: PARITY UNPINNED, as for the fixed-force main.
+
+Tolerances: f64 kernel vs oracle on the same stream -- (theta, phi), generator state, acceptance counts
+and step sizes BIT-EXACT; running sums 1e-9 relative (the kernel accumulates O(1) differences where
+the oracle recomputes, and device libm differs from glibc in the last ulp).  f32 kernel: pooled means
+within 4.5 standard errors of the oracle's (two-sample z).
+"""
+import numpy as np
+import pytest
+
+from helpers import both, pooled
+
+pytestmark = pytest.mark.gpu
+
+CLUSTER = dict(move_set=1)
+
+
+@pytest.fixture(scope="module")
+def ps():
+    import polymer_stats_amd as ps
+    assert ps._lib.load().pstat_device_count() >= 1, "no HIP device visible"
+    return ps
+
+
+def _pair(ps, nsteps, nchains, precision, burn_sched=(), burn_in=0, **kw):
+    op, pp = both(nsteps, num_chains=nchains, precision=precision, **kw)
+    if burn_sched:
+        op.burn_nsched = len(burn_sched)
+        op.burn_in = burn_in
+        for i, v in enumerate(burn_sched):
+            op.burn_sched[i] = v
+    pp.move_set = ps.MOVES_CLUSTER
+    return op, pp
+
+
+def _run_gpu(e, pp, nsteps, burn_sched=(), burn_in=0):
+    """The main's driver: every rung of the burn-in ladder and the production run are fresh mcmc() calls
+    (mcmc_clustering_eap_chain.jl:365-392)."""
+    for f in burn_sched:
+        e.set_kT(pp.kT * f)
+        e.reset_sampler()
+        e.reset_averages()
+        e.advance(burn_in)
+    e.set_kT(pp.kT)
+    e.reset_sampler()
+    e.reset_averages()
+    e.advance(nsteps)
+    e.sync()
+
+
+def _bit_parity(ps, oracle, nsteps, nchains, burn_sched=(), burn_in=0, **kw):
+    op, pp = _pair(ps, nsteps, nchains, ps.F64, burn_sched, burn_in, **kw)
+    with ps.Ensemble(pp) as e:
+        _run_gpu(e, pp, nsteps, burn_sched, burn_in)
+        for c in range(nchains):
+            o = oracle.run(op, chain_id=c, mode="cluster", trace=True)
+            g = e.chain_state(c)
+            x = e.chain_extras(c)
+            assert np.array_equal(g["theta"], o.final_theta), f"theta differs, chain {c}"
+            assert np.array_equal(g["phi"], o.final_phi), f"phi differs, chain {c}"
+            assert np.array_equal(g["rng"], o.rng), f"rng differs, chain {c}"
+            assert g["nacc_total"] == o.nacc_total
+            assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step
+            # value / normalizer: with --umbrella-sampling the gauge constant of the weights cancels
+            np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(x["sums"] / g["normalizer"], o.extra_sums / o.norm, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(e.microstate(c), np.r_[o.r, o.p, o.U], rtol=1e-9, atol=1e-8)
+
+
+@pytest.mark.parametrize("rng", [0, 1])
+def test_f64_bit_parity_cluster_dielectric(ps, oracle, rng):
+    # BASELINE configs[4] family: bending stiffness + cluster flips, adaptation active
+    _bit_parity(ps, oracle, 6000, 66, n=20, E0=1.2, K1=1.0, K2=0.2, Fz=0.7, kT=1.0, seed=21, rng=rng,
+                bend_mod=0.5, bend_angle=0.3, cluster_prob=0.5, steps_per_adjust=500)
+
+
+def test_f64_bit_parity_cluster_polar_fx(ps, oracle):
+    _bit_parity(ps, oracle, 4000, 64, n=17, E0=0.8, mu=0.9, Fz=0.3, Fx=0.25, kT=0.8, b=1.2, chain_type=1,
+                seed=22, bend_mod=0.2, bend_angle=0.0, cluster_prob=0.3, steps_per_adjust=400)
+
+
+def test_f64_bit_parity_cluster_ising(ps, oracle):
+    # Weak coupling and a short run on purpose: under the reference's Ising energy a reflected cluster
+    # end can land anti-parallel to its neighbour, r = x_i - x_{i+1} -> 0 and U -> -1e7 within a few
+    # thousand steps (polar chains at any coupling).  In that collapsed state a 1e-12 relative
+    # difference in r (cumsum positions vs. b/2 (n_i + n_j)) already moves accept decisions, so
+    # bit parity is only meaningful before the collapse.
+    _bit_parity(ps, oracle, 2000, 64, n=17, E0=1.0, K1=0.3, K2=0.02, Fz=0.3, Fx=0.25, kT=0.8, b=1.2,
+                energy_type=2, seed=22, bend_mod=0.2, bend_angle=0.0, cluster_prob=0.3, steps_per_adjust=400)
+
+
+def test_f64_bit_parity_cluster_always_and_never(ps, oracle):
+    # cluster_prob = 0: a cluster flip rides on every proposal; = 1: never (the plain single move + bending)
+    _bit_parity(ps, oracle, 3000, 64, n=12, E0=1.0, Fz=0.5, seed=23, cluster_prob=0.0, steps_per_adjust=300)
+    _bit_parity(ps, oracle, 3000, 64, n=12, E0=1.0, Fz=0.5, seed=23, cluster_prob=1.0, bend_mod=1.0,
+                bend_angle=0.5, steps_per_adjust=300)
+    _bit_parity(ps, oracle, 2000, 64, n=2, E0=1.0, Fz=0.5, seed=24, cluster_prob=0.2)
+
+
+def test_f64_bit_parity_burn_in_ladder_and_x0(ps, oracle):
+    # the annealing ladder: each rung restarts step sizes / acceptor / averagers at kT * factor
+    _bit_parity(ps, oracle, 3000, 64, burn_sched=(10.0, 2.0, 1.0), burn_in=1500, n=16, E0=1.0, Fz=0.6, kT=0.9,
+                seed=25, bend_mod=0.3, cluster_prob=0.5, steps_per_adjust=500)
+    # --x0 "[phi; theta]" --dx0: start near a given orientation instead of uniformly
+    _bit_parity(ps, oracle, 2000, 64, n=16, E0=1.0, Fz=0.6, seed=26, cluster_prob=0.5, use_x0=1, x0_phi=0.3,
+                x0_theta=1.2, dx0_phi=2 * np.pi, dx0_theta=0.1)
+
+
+def test_f64_bit_parity_cluster_umbrella(ps, oracle):
+    _bit_parity(ps, oracle, 3000, 64, n=14, E0=1.5, K1=1.0, K2=0.0, Fz=0.2, seed=27, umbrella=1,
+                bend_mod=0.4, bend_angle=0.2, cluster_prob=0.5, steps_per_adjust=500)
+
+
+@pytest.mark.parametrize("energy_type,K1", [(0, 1.0), (2, 0.2)])
+def test_f32_cluster_statistics(ps, oracle, energy_type, K1):
+    kw = dict(n=20, E0=1.0, K1=K1, K2=0.1 * K1, Fz=0.8, kT=1.0, seed=31, bend_mod=0.5, bend_angle=0.3,
+              cluster_prob=0.5, energy_type=energy_type)
+    nsteps, burn = 20000, 3000
+    op, pp = _pair(ps, nsteps, 4096, ps.F32, (1.0,), burn, **kw)
+    with ps.Ensemble(pp) as e:
+        _run_gpu(e, pp, nsteps, (1.0,), burn)
+        s = e.summary()
+    gm, gs = np.array(s.avg), np.array(s.stderr)
+    gx, gxs = np.array(s.extra_avg), np.array(s.extra_stderr)
+    nref = 768
+    sums, norm, nacc = oracle.run_many(op, 1 << 20, nref, nthreads=8, mode="cluster")
+    om, os_ = pooled(sums, norm)
+    z = (gm - om) / np.sqrt(gs ** 2 + os_ ** 2 + 1e-300)
+    assert np.all(np.abs(z) < 4.5), (z, gm, om)
+    oar = nacc / nsteps
+    zar = (s.acceptance_ratio - oar.mean()) / np.hypot(s.ar_stderr, oar.std(ddof=1) / np.sqrt(nref))
+    assert abs(zar) < 4.5, (s.acceptance_ratio, oar.mean())
+    # the two extra averagers against single-chain oracle runs
+    ex = np.array([oracle.run(op, chain_id=(1 << 20) + c, mode="cluster").extra_sums / nsteps for c in range(96)])
+    zx = (gx - ex.mean(0)) / np.sqrt(gxs ** 2 + ex.var(0, ddof=1) / len(ex))
+    assert np.all(np.abs(zx) < 4.5), (zx, gx, ex.mean(0))
+
+
+def test_cluster_full_size_properties(ps):
+    """Reference-scale ensemble (no oracle): segment invariance, checkpoint round trip, cluster_prob = 1
+    leaves the equilibrium of the plain sampler (closed form for E0 = 0, kappa = 0)."""
+    pp = ps.default_params(n=100, E0=0.0, Fz=1.0, kT=1.0, num_chains=16384, seed=41, precision=ps.F64,
+                           move_set=ps.MOVES_CLUSTER, cluster_prob=0.5)
+    with ps.Ensemble(pp) as a, ps.Ensemble(pp) as b:
+        a.advance(3000)
+        blob = a.checkpoint()
+        a.advance(2000)
+        b.advance(1000); b.advance(2000)
+        b.restore(blob)
+        b.advance(2000)
+        a.sync(); b.sync()
+        for c in (0, 777, 16383):
+            ga, gb = a.chain_state(c), b.chain_state(c)
+            assert np.array_equal(ga["theta"], gb["theta"]) and np.array_equal(ga["rng"], gb["rng"])
+            assert np.array_equal(ga["sums"], gb["sums"])
+        info = a.launch_info()
+        assert b"cluster_kernel" in info.kernel
+    # Langevin: <r3>/(n b) = coth(F b/kT) - kT/(F b)
+    pp = ps.default_params(n=100, E0=0.0, Fz=1.0, kT=1.0, num_chains=16384, seed=42, precision=ps.F32,
+                           move_set=ps.MOVES_CLUSTER, cluster_prob=1.0)
+    with ps.Ensemble(pp) as e:
+        e.advance(40000)
+        e.reset_averages()
+        e.advance(20000)
+        s = e.summary()
+    want = 100 * (1 / np.tanh(1.0) - 1.0)
+    assert abs(s.avg[2] - want) < 5 * s.stderr[2] + 1e-3 * want, (s.avg[2], want, s.stderr[2])
+
+
+def test_cluster_errors(ps):
+    for bad in (dict(energy_type=1), dict(precision=ps.Q16)):
+        with pytest.raises(ps.PstatError) as ei:
+            ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, n=16, **bad))
+        assert ei.value.code == -4
+    with ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, n=16, num_chains=64)) as e:
+        with pytest.raises(ps.PstatError):
+            e.reinit(True)

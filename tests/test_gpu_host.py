@@ -57,3 +57,44 @@ def test_cli_multi_init_and_umbrella_run(tmp_path):
     assert len(buf.getvalue().strip().splitlines()) == 10
     roll = open(prefix + "_rolling.csv").read().strip().splitlines()
     assert [r.split(",")[0] for r in roll[1:]] == ["1000.0", "2000.0", "1000.0", "2000.0"]   # step restarts per init
+
+
+def test_clustering_cli_outputs_and_oracle(tmp_path, oracle):
+    """The clustering main end to end: burn-in ladder, twelve stdout lines, the two CSV files with the
+    clustering main's extra columns (mcmc_clustering_eap_chain.jl:250-257,312-340,394-405); numbers
+    against the oracle's literal restatement run under the same options."""
+    from polymer_stats_amd import mcmc_clustering_eap_chain as host
+    prefix = str(tmp_path / "cl")
+    n, N, burn = 12, 6000, 1500
+    argv = ["-n", str(n), "-e", "1.0", "-F", "0.5", "-u", "noninteracting", "-a", "0.5", "-g", "0.2", "--cluster-prob", "0.5",
+            "-N", str(N), "--burn-in", str(burn), "--burn-schedule", "[10; 1]", "-s", "2000", "-v", "0", "-U", "0.55",
+            "--num-chains", "2048", "--seed", "4", "--prefix", prefix]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert host.main(argv) == 0
+    lines = buf.getvalue().strip().splitlines()
+    keys = [l.split("=")[0].strip() for l in lines]
+    assert keys == ["<r>", "<r/nb>", "<rj2>", "<r2>", "<p>", "<pj2>", "<p2>", "<U>", "<U2>", "<cos2(θ)>", "<ψ>", "AR"]
+    vals = {k: np.array(eval(l.split("=")[1]), dtype=float) for k, l in zip(keys, lines)}
+    traj = open(prefix + "_trajectory.csv").read().strip().splitlines()
+    roll = open(prefix + "_rolling.csv").read().strip().splitlines()
+    assert traj[0] == host.traj_header(n) and roll[0] == host.ROLL_HEADER
+    assert [r.split(",")[0] for r in roll[1:]] == ["2000.0", "4000.0", "6000.0"]      # only the production run's rows
+    assert all(len(r.split(",")) == 8 + 5 * n for r in traj[1:]) and all(len(r.split(",")) == 19 for r in roll[1:])
+    last = np.array([float(x) for x in roll[-1].split(",")])
+    np.testing.assert_allclose(last[17:19], [vals["<cos2(θ)>"], vals["<ψ>"]], rtol=1e-12)
+    row = np.array([float(x) for x in traj[-1].split(",")])
+    ang = row[8:8 + 2 * n].reshape(n, 2)
+    mus = row[8 + 2 * n:].reshape(n, 3)
+    np.testing.assert_allclose(mus.sum(0), row[4:7], rtol=1e-5, atol=1e-6)             # p = sum of the mu_i columns
+    np.testing.assert_allclose(np.cos(ang[:, 1]).sum(), row[3], rtol=1e-5, atol=1e-5)  # r3 = b sum cos(theta_i)
+
+    P = oracle.make_params(n=n, E0=1.0, Fz=0.5, bend_mod=0.5, bend_angle=0.2, cluster_prob=0.5, num_steps=N, seed=4,
+                           burn_in=burn, burn_sched=[10.0, 1.0], adj_ub=0.55)
+    sums, norm, nacc = oracle.run_many(P, 10 ** 6, 384, nthreads=8, mode="cluster")
+    m = sums / norm[:, None]
+    se = m.std(0, ddof=1) / np.sqrt(m.shape[0])
+    got = np.r_[vals["<r>"], vals["<rj2>"], vals["<r2>"], vals["<p>"], vals["<pj2>"], vals["<p2>"], vals["<U>"], vals["<U2>"]]
+    z = (got - m.mean(0)) / (se * 1.1 + 1e-12)
+    assert np.all(np.abs(z) < 4.5), z
+    assert abs(float(vals["AR"]) - nacc.mean() / N) < 0.01

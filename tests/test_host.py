@@ -95,9 +95,83 @@ def test_summary_from_reduction_is_pooled_mean_and_stderr():
     red = np.zeros(ps.NRED)
     red[0] = C
     red[1:18] = m.sum(0)
-    red[18:35] = (m ** 2).sum(0)
+    red[1 + ps.NQ:1 + ps.NQ + 17] = (m ** 2).sum(0)
     s = ps.summary_from_reduction(red, 1000)
     np.testing.assert_allclose(np.array(s.avg), m[:, :16].mean(0), rtol=1e-13)
     np.testing.assert_allclose(np.array(s.stderr), m[:, :16].std(0, ddof=1) / np.sqrt(C), rtol=1e-9)
     assert s.acceptance_ratio == pytest.approx(m[:, 16].mean())
     assert s.num_chains == C and s.steps_per_chain == 1000 and s.attempted_updates == C * 1000.0
+
+
+# ------------------------------------------------------------------ clustering main's host twin
+from polymer_stats_amd import mcmc_clustering_eap_chain as chost
+
+# (long flag, short alias, default) read off mcmc_clustering_eap_chain.jl:14-152
+CLUSTER_TABLE = [
+    ("--E0", "-e", 0.0), ("--chain-type", "-T", "dielectric"), ("--K1", "-J", 1.0), ("--K2", "-K", 0.0),
+    ("--mu", "-m", 1e-2), ("--bend-mod", "-a", 0.0), ("--bend-angle", "-g", 0.0), ("--energy-type", "-u", "Ising"),
+    ("--cutoff-radius", None, 7.5), ("--kT", "-k", 1.0), ("--Fz", "-F", 0.0), ("--Fx", "-G", 0.0),
+    ("--mlen", "-b", 1.0), ("--num-monomers", "-n", 100), ("--num-steps", "-N", 1000000),
+    ("--phi-step", "-p", 3 * math.pi / 8), ("--theta-step", "-q", 3 * math.pi / 16), ("--cluster-prob", None, 0.5),
+    ("--step-adjust-lb", "-L", 0.15), ("--step-adjust-ub", "-U", 0.40), ("--step-adjust-scale", "-A", 1.1),
+    ("--steps-per-adjust", "-S", 2500), ("--umbrella-sampling", "-B", False), ("--update-freq", None, 15.0),
+    ("--verbose", "-v", 3), ("--prefix", "-P", "eap-mcmc"), ("--postfix", "-Q", ""), ("--stepout", "-s", 500),
+    ("--numeric-type", None, "float64"), ("--burn-in", None, 50000),
+    ("--burn-schedule", None, "[1000; 100; 10; 2; 1]"), ("--dx0", None, "[2*pi, 1e-1]"), ("--profile", "-Z", False),
+]
+
+
+def test_cluster_option_table_matches_reference():
+    d = chost.parse_args([])
+    assert d["x0"] is None                      # no default: EAPChain(pargs) then draws uniform angles
+    for long, short, default in CLUSTER_TABLE:
+        key = long[2:]
+        assert d[key] == default and type(d[key]) is type(default), (key, d[key], default)
+        if short is not None:
+            val = {bool: None, int: "7", float: "0.25", str: "polar"}[type(default)]
+            got = chost.parse_args([short] if val is None else [short, val])[key]
+            assert got == (True if val is None else type(default)(val)), (short, got)
+    assert len(CLUSTER_TABLE) + 1 == 34         # the reference's table has 34 entries (x0 is the 34th)
+
+
+def test_cluster_julia_vector_literals_and_params():
+    assert chost.julia_vector("[2*pi, 1e-1]") == [2 * math.pi, 0.1]
+    assert chost.julia_vector("[1000; 100; 10; 2; 1]") == [1000.0, 100.0, 10.0, 2.0, 1.0]
+    assert chost.julia_vector("[]") == [] and chost.julia_vector("[π/2; -0.3]") == [math.pi / 2, -0.3]
+    for bad in ("1, 2", "[__import__('os')]", "[a]", "[1; f(2)]"):
+        with pytest.raises((ValueError, SyntaxError)):
+            chost.julia_vector(bad)
+    p = chost.params_from_pargs(chost.default_pargs(**{"x0": "[0.3; 1.2]", "bend-mod": 2.0, "bend-angle": 0.1,
+                                                       "cluster-prob": 0.25, "energy-type": "noninteracting"}), 128, 64, 0)
+    assert (p.move_set, p.use_x0, p.x0_phi, p.x0_theta, p.dx0_phi, p.dx0_theta) == (ps.MOVES_CLUSTER, 1, 0.3, 1.2, 2 * math.pi, 0.1)
+    assert (p.bend_mod, p.bend_angle, p.cluster_prob, p.energy_type, p.adj_ub) == (2.0, 0.1, 0.25, ps.NONINTERACTING, 0.40)
+    assert chost.params_from_pargs(chost.default_pargs(), 1, 0, 0).energy_type == ps.ISING
+    with pytest.raises(host.ReferenceError_, match="Invalid input for 'x0'"):
+        chost.params_from_pargs(chost.default_pargs(x0="[1; 2; 3]"), 1, 0, 0)
+    with pytest.raises(host.ReferenceError_, match="energy-type is not understood."):
+        chost.params_from_pargs(chost.default_pargs(**{"energy-type": "x"}), 1, 0, 0)
+    for et in ("interacting", "cutoff"):
+        with pytest.raises(ps.PstatError) as ei:
+            chost.params_from_pargs(chost.default_pargs(**{"energy-type": et}), 1, 0, 0)
+        assert ei.value.code == -4
+    with pytest.raises(host.ReferenceError_):
+        chost.main(["--profile"])
+
+
+def test_cluster_output_shapes():
+    assert chost.traj_header(2) == "step,r1,r2,r3,p1,p2,p3,U,phi1,theta1,phi2,theta2,mux1,muy1,muz1,mux2,muy2,muz2"
+    assert chost.ROLL_HEADER.split(",")[-2:] == ["Ealign", "psi"] and len(chost.ROLL_HEADER.split(",")) == 19
+    avg = np.arange(1.0, 17.0)
+    sas = [host.Averager(avg[6], 0), host.Averager(avg[13], 0), host.Averager(avg[14], 0), host.Averager(avg[15], 0),
+           host.Averager(33.5, 0), host.Averager(1.25, 0)]
+    vas = [host.Averager(avg[0:3], 0), host.Averager(avg[3:6], 0), host.Averager(avg[7:10], 0), host.Averager(avg[10:13], 0)]
+    lines = chost.summary_lines(sas, vas, 0.3, chost.default_pargs(**{"num-monomers": 10}))
+    assert [l.split("=")[0].strip() for l in lines] == ["<r>", "<r/nb>", "<rj2>", "<r2>", "<p>", "<pj2>", "<p2>", "<U>",
+                                                        "<U2>", "<cos2(θ)>", "<ψ>", "AR"]
+    assert lines[9] == "<cos2(θ)>   =   33.5" and lines[10] == "<ψ>    =   1.25" and lines[11] == "AR     =   0.3"
+    # dipoles written to the trajectory file (inc/dipole_response.jl:7-29)
+    pa = chost.default_pargs(E0=2.0, K1=1.0, K2=0.25)
+    mu = chost._dipoles(pa, np.array([0.0]), np.array([0.0]))
+    np.testing.assert_allclose(mu, [[0.0, 0.0, 2.0]])           # n = z: mu = K1 E0 z
+    mu = chost._dipoles(pa, np.array([0.0]), np.array([math.pi / 2]))
+    np.testing.assert_allclose(mu, [[0.0, 0.0, 0.5]], atol=1e-15)   # n = x: mu = K2 E0 z

@@ -2,7 +2,7 @@
 """BASELINE configs[4]: (E0, kT) phase-diagram scan at n = 200 (grid of run/K1_E0-kT-phase.jl:21-24:
 E0 in 0:0.2:5, kT in 10^(-2:0.2:2), K1 = 1, K2 = 0, b = 1, F = 0), all 546 grid points in ONE
 batched launch per GPU.  Chains of every grid point are sharded over the ranks by global chain id;
-the only exchange is one all-reduce(SUM) of the [points x 35] reduction tensor (RCCL when launched
+the only exchange is one all-reduce(SUM) of the [points x 39] reduction tensor (RCCL when launched
 with torch.distributed.run, nothing at all for one GPU).
 
     python tools/phase_scan.py --chains 128 --steps 50000 --burn-in 20000 --energy Ising --out scan.csv
