@@ -9,6 +9,9 @@
  *                      accepted state.
  *   eap_run_fast     : the same Markov chain (same stream, same decisions up to fp rounding)
  *                      with an O(1) energy difference; this is the form the HIP kernels use.
+ *   eap_run_cluster  : mcmc_clustering_eap_chain.jl, literally: deep copy, move!, cluster_flip! with a
+ *                      full recomputation per reflected member, bending energy, the acceptor caching
+ *                      log(pi) + log(alpha), the burn-in ladder of fresh mcmc() calls.
  *
  * Random stream contract (ours; the reference is unseeded, mcmc_eap_chain.jl has no seed):
  *   generator, one per chain (eap_params.rng):
@@ -22,6 +25,11 @@
  *   step    : idx = mulhi32(w, n); dphi = phi_step*(2u-1); [flip bit = w>>31 if --do-flips];
  *             dtheta = theta_step*(2u-1); eps = u                              (mcmc_eap_chain.jl:277-287)
  *   re-init : 2n init draws, then eps = u unless --force-init                  (:353-358)
+ *   clustering main (eap_run_cluster), per step: idx, dphi, dtheta as above; then the cluster's draws --
+ *             skip = u (no cluster if skip <= cluster_prob), then per round one draw for the link
+ *             above the cluster while that end grows and one for the link below while that end grows
+ *             (the reference finishes the upper loop before the lower one; same law, see cluster_flip)
+ *             -- and eps = u last.  --x0 start: phi_i = x0_phi + dx0_phi*u (all i), then theta likewise.
  */
 #include "eap_oracle.h"
 
@@ -485,21 +493,28 @@ int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, ea
 static double cluster_flip(const eap_params *P, uint32_t rng[5], chain_t *c, int64_t idx) {
   if (draw_u(rng) <= P->cluster_prob) return 1.0;                                  /* :276 */
   const int64_t n = c->n;
-  double upper_p, lower_p;
+  double upper_p = 0.0, lower_p = 0.0;
   int64_t upper = idx, lower = idx;
-  for (;;) {                                                                        /* :281-292 */
-    if (upper >= n - 1) { upper_p = 0.0; break; }
-    double d = c->nh[3 * upper] * c->nh[3 * upper + 3] + c->nh[3 * upper + 1] * c->nh[3 * upper + 4] +
-               c->nh[3 * upper + 2] * c->nh[3 * upper + 5];
-    upper_p = (1 + d) / 2;
-    if (draw_u(rng) <= upper_p) ++upper; else break;
-  }
-  for (;;) {                                                                        /* :298-309 */
-    if (lower <= 0) { lower_p = 0.0; break; }
-    double d = c->nh[3 * lower] * c->nh[3 * lower - 3] + c->nh[3 * lower + 1] * c->nh[3 * lower - 2] +
-               c->nh[3 * lower + 2] * c->nh[3 * lower - 1];
-    lower_p = (1 + d) / 2;
-    if (draw_u(rng) <= lower_p) --lower; else break;
+  /* :281-309.  The reference grows the upper end to completion, then the lower end.  Here the two
+   * loops are interleaved -- per round one link test above (if that end is still growing), then one
+   * below -- which is the stream contract shared with the device kernel.  The two ends read disjoint
+   * links and every test has its own iid draw, so the law of (lower, upper) is unchanged. */
+  int gu = upper < n - 1, gl = lower > 0;     /* at a chain end: p = 0, no draw (:282-284,299-301) */
+  while (gu || gl) {
+    if (gu) {
+      double d = c->nh[3 * upper] * c->nh[3 * upper + 3] + c->nh[3 * upper + 1] * c->nh[3 * upper + 4] +
+                 c->nh[3 * upper + 2] * c->nh[3 * upper + 5];
+      upper_p = (1 + d) / 2;
+      if (draw_u(rng) <= upper_p) { ++upper; if (upper >= n - 1) { upper_p = 0.0; gu = 0; } }
+      else gu = 0;
+    }
+    if (gl) {
+      double d = c->nh[3 * lower] * c->nh[3 * lower - 3] + c->nh[3 * lower + 1] * c->nh[3 * lower - 2] +
+                 c->nh[3 * lower + 2] * c->nh[3 * lower - 1];
+      lower_p = (1 + d) / 2;
+      if (draw_u(rng) <= lower_p) { --lower; if (lower <= 0) { lower_p = 0.0; gl = 0; } }
+      else gl = 0;
+    }
   }
   for (int64_t i = lower; i <= upper; ++i) chain_move(P, c, i, 0.0, M_PI - 2 * c->th[i]);  /* refl_n!, :263-265,314-316 */
   double new_upper_p = 0.0, new_lower_p = 0.0;                                      /* :318-327 */

@@ -35,7 +35,21 @@ template <typename R> struct V3 { R x, y, z; };
 template <typename R> __device__ __forceinline__ R dot3(const V3<R> &a, const V3<R> &b) {
   return a.x * b.x + a.y * b.y + a.z * b.z;
 }
-__device__ __forceinline__ float acos_r(float x) { return acosf(x); }
+// acos on [-1, 1] as sqrt(1 - |x|) * P7(|x|) (Abramowitz & Stegun 4.4.46, |error| <= 2e-8 -- below the
+// f32 spacing of the result), mirrored for x < 0: a dozen full-rate ops and one v_sqrt
+__device__ __forceinline__ float acos_r(float x) {
+  const float a = fabsf(x);
+  float p = -0.0012624911f;
+  p = __builtin_fmaf(p, a, 0.0066700901f);
+  p = __builtin_fmaf(p, a, -0.0170881256f);
+  p = __builtin_fmaf(p, a, 0.0308918810f);
+  p = __builtin_fmaf(p, a, -0.0501743046f);
+  p = __builtin_fmaf(p, a, 0.0889789874f);
+  p = __builtin_fmaf(p, a, -0.2145988016f);
+  p = __builtin_fmaf(p, a, 1.5707963050f);
+  const float r = __builtin_amdgcn_sqrtf(fmaxf(1.0f - a, 0.0f)) * p;
+  return x < 0.0f ? 3.14159265358979f - r : r;
+}
 __device__ __forceinline__ double acos_r(double x) { return acos(x); }
 __device__ __forceinline__ float log_r(float x) { return __logf(x); }
 __device__ __forceinline__ double log_r(double x) { return log(x); }
@@ -105,14 +119,32 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
 
   // n-hat and dipole of monomer i from its stored angles
   // (returns whether theta sits exactly on a clamp value, see `edge` below)
-  auto load_nm = [&](const int i, T3 &nh, T3 &mu) __attribute__((always_inline)) -> bool {
-    const R2 a = ang[i * lanes + lane];
+  auto nm_of = [&](const R2 a, T3 &nh, T3 &mu) __attribute__((always_inline)) -> bool {
     R s, co, sp, cp;
     AG::sc(a.x, &s, &co);
     AG::sc(a.y, &sp, &cp);
     nh.x = cp * s; nh.y = sp * s; nh.z = co;
     dipole<R, CT>(a_or_mu, k2e, nh.x, nh.y, nh.z, mu.x, mu.y, mu.z);
     return a.x == (R)0 || a.x == AG::theta_max;
+  };
+  auto nhat_of = [&](const R2 a, T3 &nh) __attribute__((always_inline)) -> bool {
+    R s, co, sp, cp;
+    AG::sc(a.x, &s, &co);
+    AG::sc(a.y, &sp, &cp);
+    nh.x = cp * s; nh.y = sp * s; nh.z = co;
+    return a.x == (R)0 || a.x == AG::theta_max;
+  };
+  // a monomer joins the cluster: its n_z and the components of its dipole that the reflection flips
+  // (dielectric: mu_x, mu_y = (K1-K2) E0 n_z (n_x, n_y); polar: mu_z = mu n_z) enter the member sums
+  auto member = [&](const bool acc, const T3 &nh, R &snz, T3 &sm) __attribute__((always_inline)) {
+    const R z = acc ? nh.z : (R)0;
+    snz += z;
+    const R q = a_or_mu * z;
+    if constexpr (CT == PSTAT_DIELECTRIC) { sm.x += q * nh.x; sm.y += q * nh.y; }
+    else sm.z += q;
+  };
+  auto load_nm = [&](const int i, T3 &nh, T3 &mu) __attribute__((always_inline)) -> bool {
+    return nm_of(ang[i * lanes + lane], nh, mu);
   };
   // reflection through the plane normal to the field: refl_n!, inc/eap_chain.jl:263-265
   auto refl_theta = [&](const R th) __attribute__((always_inline)) -> R {
@@ -193,52 +225,83 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
         edge = th1 == (R)0 || th1 == AG::theta_max;
         R snz = n1.z;                 // sums over the members (the moved monomer enters as proposed)
         T3 sm = m1;
-        R upper_p, lower_p, new_upper_p = 0, new_lower_p = 0;
-        {  // grow towards the chain end, :281-292
-          T3 cur = n1, curm = m1, nxt = nR, nxtm = mR;
-          bool nxt_edge = edgeR;
-          for (;;) {
-            if (upper >= n - 1) { upper_p = 0; break; }
-            upper_p = (1 + dot3(cur, nxt)) / 2;
-            if (!(u01<R>(g.next()) <= upper_p)) break;
-            ++upper;
-            cur = nxt; curm = nxtm;
-            edge = edge || nxt_edge;
-            snz += cur.z; sm.x += curm.x; sm.y += curm.y; sm.z += curm.z;
-            if (upper < n - 1) nxt_edge = load_nm(upper + 1, nxt, nxtm);
+        R upper_p = 0, lower_p = 0, new_upper_p = 0, new_lower_p = 0;
+        // Both ends grow in ONE loop: round t tests the link above the cluster, (idx+t, idx+t+1), then
+        // the link below it, (idx-t, idx-t-1), each with its own draw while that end is still growing
+        // (the stream contract; the reference runs the two loops one after the other, :281-309 -- the
+        // links are disjoint and the draws iid, so the law of (lower, upper) is the same).
+        // Every lane that is still growing at round t has accepted exactly t links on that side, so
+        // the rows visited depend on t only: the n-hats shift down a window (A <- B <- prefetched)
+        // without selects, the row two away is read and converted speculatively, and the only
+        // predicated state is the generator, the extents, the member sums and the clamp flag.
+        T3 Au = n1, Bu = nR, Al = n1, Bl = nL;
+        bool eBu = edgeR, eBl = edgeL;
+        bool gu = hasR, gl = hasL;
+        int rowu = min(idx + 2, n - 1), rowl = max(idx - 2, 0);
+        R2 au = ang[rowu * lanes + lane], al = ang[rowl * lanes + lane];
+        while (gu || gl) {
+          T3 Cu, Cl;
+          const bool eCu = nhat_of(au, Cu), eCl = nhat_of(al, Cl);
+          rowu = min(rowu + 1, n - 1); rowl = max(rowl - 1, 0);
+          au = ang[rowu * lanes + lane]; al = ang[rowl * lanes + lane];
+          {
+            const R p = (1 + dot3(Au, Bu)) / 2;
+            G g2 = g;
+            const bool acc = gu && (u01<R>(g2.next()) <= p);
+            g.pick(gu, g2);
+            upper_p = gu ? p : upper_p;
+            upper += acc ? 1 : 0;
+            edge = edge || (acc && eBu);
+            member(acc, Bu, snz, sm);
+            gu = acc && upper < n - 1;
+            Au = Bu; Bu = Cu; eBu = eCu;
           }
-          if (upper < n - 1) {  // boundary bond (upper, upper+1) before and after the reflection, :318-321
-            const T3 rf = refl_n(cur), rfm = refl_mu(curm);
+          {
+            const R p = (1 + dot3(Al, Bl)) / 2;
+            G g2 = g;
+            const bool acc = gl && (u01<R>(g2.next()) <= p);
+            g.pick(gl, g2);
+            lower_p = gl ? p : lower_p;
+            lower -= acc ? 1 : 0;
+            edge = edge || (acc && eBl);
+            member(acc, Bl, snz, sm);
+            gl = acc && lower > 0;
+            Al = Bl; Bl = Cl; eBl = eCl;
+          }
+        }
+        upper_p = upper >= n - 1 ? (R)0 : upper_p;   // ran into the chain end: no link to test, :282-284
+        lower_p = lower <= 0 ? (R)0 : lower_p;       // :299-301
+        // the two boundary bonds, before and after the reflection (:318-326); their monomers are read
+        // back from LDS (the moved monomer enters as proposed)
+        {
+          T3 cu, cum, nu, num, cl, clm, nl, nlm;
+          load_nm(upper, cu, cum);
+          load_nm(min(upper + 1, n - 1), nu, num);
+          load_nm(lower, cl, clm);
+          load_nm(max(lower - 1, 0), nl, nlm);
+          if (upper == idx) { cu = n1; cum = m1; }
+          if (lower == idx) { cl = n1; clm = m1; }
+          if (upper < n - 1) {
+            const T3 rf = refl_n(cu), rfm = refl_mu(cum);
             R p0, e0, q0, p1, e1, q1;
-            bond(cur, curm, nxt, nxtm, p0, e0, q0);
-            bond(rf, rfm, nxt, nxtm, p1, e1, q1);
-            new_upper_p = (1 + dot3(rf, nxt)) / 2;
+            bond(cu, cum, nu, num, p0, e0, q0);
+            bond(rf, rfm, nu, num, p1, e1, q1);
+            new_upper_p = (1 + dot3(rf, nu)) / 2;
+            dpsi_flip += p1 - p0; du_flip += e1 - e0; dpair_flip += q1 - q0;
+          }
+          if (lower > 0) {
+            const T3 rf = refl_n(cl), rfm = refl_mu(clm);
+            R p0, e0, q0, p1, e1, q1;
+            bond(nl, nlm, cl, clm, p0, e0, q0);
+            bond(nl, nlm, rf, rfm, p1, e1, q1);
+            new_lower_p = (1 + dot3(rf, nl)) / 2;
             dpsi_flip += p1 - p0; du_flip += e1 - e0; dpair_flip += q1 - q0;
           }
         }
-        {  // grow towards the chain start, :298-309
-          T3 cur = n1, curm = m1, nxt = nL, nxtm = mL;
-          bool nxt_edge = edgeL;
-          for (;;) {
-            if (lower <= 0) { lower_p = 0; break; }
-            lower_p = (1 + dot3(cur, nxt)) / 2;
-            if (!(u01<R>(g.next()) <= lower_p)) break;
-            --lower;
-            cur = nxt; curm = nxtm;
-            edge = edge || nxt_edge;
-            snz += cur.z; sm.x += curm.x; sm.y += curm.y; sm.z += curm.z;
-            if (lower > 0) nxt_edge = load_nm(lower - 1, nxt, nxtm);
-          }
-          if (lower > 0) {      // boundary bond (lower-1, lower), :323-326
-            const T3 rf = refl_n(cur), rfm = refl_mu(curm);
-            R p0, e0, q0, p1, e1, q1;
-            bond(nxt, nxtm, cur, curm, p0, e0, q0);
-            bond(nxt, nxtm, rf, rfm, p1, e1, q1);
-            new_lower_p = (1 + dot3(rf, nxt)) / 2;
-            dpsi_flip += p1 - p0; du_flip += e1 - e0; dpair_flip += q1 - q0;
-          }
-        }
-        alpha = ((1 - new_upper_p) * (1 - new_lower_p)) / ((1 - upper_p) * (1 - lower_p));   // :328-329
+        if constexpr (sizeof(R) == 8)
+          alpha = ((1 - new_upper_p) * (1 - new_lower_p)) / ((1 - upper_p) * (1 - lower_p));   // :328-329
+        else
+          alpha = ((1 - new_upper_p) * (1 - new_lower_p)) * __builtin_amdgcn_rcpf((1 - upper_p) * (1 - lower_p));
         // members' own terms: n_z -> -n_z; dielectric mu -> (-mu_x, -mu_y, mu_z), polar mu_z -> -mu_z
         drz_flip = b * (-2 * snz);
         if constexpr (CT == PSTAT_DIELECTRIC) { dp_flip.x = -2 * sm.x; dp_flip.y = -2 * sm.y; }
@@ -272,11 +335,18 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
         a1.y = ph1;
         ang[cell] = a1;
         if (flipped) {
-          for (int i = lower; i <= upper; ++i) {
-            if (i == idx) continue;
-            R2 v = ang[i * lanes + lane];
-            v.x = refl_theta(v.x);
-            ang[i * lanes + lane] = v;
+          // four members per pass: the reads are independent, slots past `upper` alias `upper` and
+          // write the same value again; the moved monomer (already stored) is passed through
+          for (int i = lower; i <= upper; i += 4) {
+            R2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ang[min(i + j, upper) * lanes + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int m = min(i + j, upper);
+              v[j].x = m == idx ? v[j].x : refl_theta(v[j].x);
+              ang[m * lanes + lane] = v[j];
+            }
           }
         }
         Orx += drx; Ory += dry; Orz += drz;

@@ -117,6 +117,10 @@ struct Xoshiro128pp {
     s3 = (s3 << 11) | (s3 >> 21);
     return result;
   }
+  // adopt the advanced copy `o` where `take` holds (branch-free conditional draw)
+  __host__ __device__ inline void pick(bool take, const Xoshiro128pp &o) {
+    s0 = take ? o.s0 : s0; s1 = take ? o.s1 : s1; s2 = take ? o.s2 : s2; s3 = take ? o.s3 : s3;
+  }
   __host__ __device__ inline void load(const uint32_t *p, int64_t stride) {
     s0 = p[0]; s1 = p[stride]; s2 = p[2 * stride]; s3 = p[3 * stride];
   }
@@ -167,6 +171,7 @@ struct Mwc64x {
     x = (uint32_t)t; c = (uint32_t)(t >> 32);
     return r;
   }
+  __host__ __device__ inline void pick(bool take, const Mwc64x &o) { x = take ? o.x : x; c = take ? o.c : c; }
   __host__ __device__ inline void load(const uint32_t *p, int64_t stride) { x = p[0]; c = p[stride]; }
   __host__ __device__ inline void store(uint32_t *p, int64_t stride) const {
     p[0] = x; p[stride] = c; p[2 * stride] = 0u; p[3 * stride] = 0u;
