@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PSTAT_ABI_VERSION 3
+#define PSTAT_ABI_VERSION 4
 
 typedef enum pstat_status {
   PSTAT_OK = 0,
@@ -43,7 +43,11 @@ typedef enum pstat_status {
 /* --chain-type (mcmc_eap_chain.jl:25-28; inc/eap_chain.jl:81-87) */
 enum { PSTAT_DIELECTRIC = 0, PSTAT_POLAR = 1 };
 /* --energy-type (mcmc_eap_chain.jl:41-44; inc/eap_chain.jl:95-105) */
-enum { PSTAT_NONINTERACTING = 0, PSTAT_INTERACTING = 1, PSTAT_ISING = 2 };
+enum { PSTAT_NONINTERACTING = 0, PSTAT_INTERACTING = 1, PSTAT_ISING = 2,
+       /* clustering main only (mcmc_clustering_eap_chain.jl:44-51; UCutoff, inc/eap_chain.jl:165-192):
+        * dipole-dipole terms of pairs within cutoff_radius monomer lengths.  NB the reference's UCutoff
+        * functor returns that sum ALONE -- with this energy neither the field nor the force enters U. */
+       PSTAT_CUTOFF = 3 };
 /* arithmetic of the device path:
  *   PSTAT_F32  f32 state and transcendentals, f64 running sums (default);
  *   PSTAT_F64  f64 throughout (the reference's Float64; bit-reproduces the CPU oracle's trajectory);
@@ -59,7 +63,8 @@ enum { PSTAT_RNG_MWC64X = 0, PSTAT_RNG_XOSHIRO128PP = 1 };
  *   PSTAT_MOVES_SINGLE   mcmc_eap_chain.jl:276-291 -- one single-monomer trial move per step (default)
  *   PSTAT_MOVES_CLUSTER  mcmc_clustering_eap_chain.jl:268-279 -- the same move followed, on the trial
  *                        chain, by cluster_flip! (inc/eap_chain.jl:269-333); bending energy; two more
- *                        averagers (sum cos^2 theta, mean bond angle).  Non-interacting and Ising. */
+ *                        averagers (sum cos^2 theta, mean bond angle).  All four energies; the all-pairs
+ *                        ones (interacting, cutoff) run one chain per wavefront, n <= 256, f32/f64. */
 enum { PSTAT_MOVES_SINGLE = 0, PSTAT_MOVES_CLUSTER = 1 };
 
 /* Flattened pargs::Dict (mcmc_eap_chain.jl:155) -- the keys the force-ensemble step loop reads. */
@@ -89,6 +94,7 @@ typedef struct pstat_params {
   double dx0_phi, dx0_theta;     /* --dx0                                                     */
   int32_t use_x0;                /* start from x0 + Uniform(0, dx0) instead of uniform angles */
   int32_t reserved;              /* must be 0                                                 */
+  double cutoff_radius;          /* --cutoff-radius, monomer lengths (PSTAT_CUTOFF; per case)  */
 } pstat_params;
 
 /* Order of every 16-vector below = the columns of <prefix>_rolling.csv after "step"

@@ -26,6 +26,7 @@ struct PstatParams
   bend_mod::Cdouble; bend_angle::Cdouble; cluster_prob::Cdouble
   x0_phi::Cdouble; x0_theta::Cdouble; dx0_phi::Cdouble; dx0_theta::Cdouble
   use_x0::Int32; reserved::Int32
+  cutoff_radius::Cdouble
 end
 
 # mirror of `pstat_summary`
@@ -118,7 +119,7 @@ function params(pargs, num_chains, chain_id0, device)
               ct, et, pargs["do-flips"] ? 1 : 0, pargs["umbrella-sampling"] ? 1 : 0, prec, device, rng,
               0,                                   # move_set = PSTAT_MOVES_SINGLE: this main
               0.0, 0.0, 0.5, 0.0, 0.0, 2pi, 0.1,   # clustering-main options at their defaults (unused here)
-              0, 0)
+              0, 0, 7.5)
 end
 
 function pooled_summary(handles, steps)

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle.so")
 
 DIELECTRIC, POLAR = 0, 1
-NONINTERACTING, INTERACTING, ISING = 0, 1, 2
+NONINTERACTING, INTERACTING, ISING, CUTOFF = 0, 1, 2, 3
 RNG_MWC64X, RNG_XOSHIRO128PP = 0, 1
 NOBS = 16
 OBS_NAMES = ["r1", "r2", "r3", "r1sq", "r2sq", "r3sq", "rsq",
@@ -35,7 +35,7 @@ class EapParams(C.Structure):
                [(k, C.c_double) for k in
                 ("bend_mod", "bend_angle", "cluster_prob", "x0_phi", "x0_theta", "dx0_phi", "dx0_theta")] + \
                [("burn_sched", C.c_double * 8), ("burn_in", C.c_int64),
-                ("burn_nsched", C.c_int32), ("use_x0", C.c_int32)]
+                ("burn_nsched", C.c_int32), ("use_x0", C.c_int32), ("cutoff_radius", C.c_double)]
 
 
 class EapResult(C.Structure):
@@ -104,7 +104,7 @@ def make_params(**kw) -> EapParams:
              seed=0, chain_type=DIELECTRIC, energy_type=NONINTERACTING,
              do_flips=0, force_init=0, umbrella=0, rng=RNG_MWC64X,
              bend_mod=0.0, bend_angle=0.0, cluster_prob=1.0, x0_phi=0.0, x0_theta=0.0,
-             dx0_phi=2 * np.pi, dx0_theta=0.1, burn_in=0, burn_nsched=0, use_x0=0)
+             dx0_phi=2 * np.pi, dx0_theta=0.1, burn_in=0, burn_nsched=0, use_x0=0, cutoff_radius=7.5)
     sched = list(kw.pop("burn_sched", []))
     unknown = set(kw) - set(d)
     if unknown:

@@ -183,6 +183,19 @@ double eap_pair_energy(int64_t n, const double *xs, const double *mus, int ising
   return U;
 }
 
+double eap_pair_energy_cutoff(int64_t n, const double *xs, const double *mus, double rc) {
+  const double crad2 = rc * rc;
+  double U = 0.0;
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = i + 1; j < n; ++j) {
+      const double *xi = xs + 3 * i, *xj = xs + 3 * j;
+      double rx = xi[0] - xj[0], ry = xi[1] - xj[1], rz = xi[2] - xj[2];
+      double r2 = rx * rx + ry * ry + rz * rz;
+      U += (r2 > crad2) ? 0.0 : pair_term(xi, xj, mus + 3 * i, mus + 3 * j);
+    }
+  return U;
+}
+
 /* ------------------------------------------------------------------ literal chain object */
 
 typedef struct chain_t { /* inc/eap_chain.jl:12-36 */
@@ -251,6 +264,10 @@ static double sum_us(const chain_t *c) {
 
 /* energy.jl:7-23 */
 static double chain_U(const eap_params *P, const chain_t *c) {
+  /* UCutoff's functor returns the truncated pair sum ALONE -- no sum(us), no -F.r (inc/eap_chain.jl:171-192
+   * vs inc/energy.jl:13-16): with --energy-type cutoff neither the field nor the force enters U. */
+  if (P->energy_type == EAP_CUTOFF)
+    return eap_pair_energy_cutoff(c->n, c->xs, c->mus, P->cutoff_radius * P->b);
   double r[3];
   end_to_end(P, c, r);
   double U = sum_us(c);
@@ -403,7 +420,7 @@ static void adapt(const eap_params *P, int64_t step, double *phistep, double *th
 static int check_params(const eap_params *P) {
   if (P->n < 1 || P->num_steps < 0 || P->num_inits < 1) return -1;
   if (P->chain_type != EAP_DIELECTRIC && P->chain_type != EAP_POLAR) return -1;
-  if (P->energy_type < 0 || P->energy_type > EAP_ISING) return -1;
+  if (P->energy_type < 0 || P->energy_type > EAP_CUTOFF) return -1;
   if (P->rng != EAP_RNG_MWC64X && P->rng != EAP_RNG_XOSHIRO128PP) return -1;
   return 0;
 }
@@ -412,6 +429,7 @@ static int check_params(const eap_params *P) {
 
 int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, eap_trace *tr) {
   if (check_params(P)) return -1;
+  if (P->energy_type == EAP_CUTOFF) return -1; /* mcmc_eap_chain.jl has no --cutoff-radius: KeyError there */
   uint32_t rng[5];
   seed_chain(P, chain_id, rng);
   chain_t cur, trial, fresh;
@@ -703,6 +721,7 @@ static double ising_bonds(const eap_params *P, const fast_t *c, int64_t idx, con
 
 int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_trace *tr) {
   if (check_params(P)) return -1;
+  if (P->energy_type == EAP_CUTOFF) return -1;
   uint32_t rng[5];
   seed_chain(P, chain_id, rng);
   fast_t c, fresh;

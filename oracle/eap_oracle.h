@@ -25,7 +25,8 @@ extern "C" {
 #endif
 
 enum { EAP_DIELECTRIC = 0, EAP_POLAR = 1 };              /* --chain-type  */
-enum { EAP_NONINTERACTING = 0, EAP_INTERACTING = 1, EAP_ISING = 2 }; /* --energy-type */
+enum { EAP_NONINTERACTING = 0, EAP_INTERACTING = 1, EAP_ISING = 2,
+       EAP_CUTOFF = 3 /* clustering main only: UCutoff, inc/eap_chain.jl:165-192 */ }; /* --energy-type */
 enum { EAP_RNG_MWC64X = 0, EAP_RNG_XOSHIRO128PP = 1 };               /* per-chain generator */
 
 /* Flat mirror of the option table mcmc_eap_chain.jl:19-153 (hot-path subset). */
@@ -54,6 +55,7 @@ typedef struct eap_params {
   int64_t burn_in;                      /* --burn-in steps per rung (:134-137) */
   int32_t burn_nsched;                  /* number of rungs used */
   int32_t use_x0;
+  double cutoff_radius;                 /* --cutoff-radius, in monomer lengths (:48-51; x mlen at inc/eap_chain.jl:102) */
 } eap_params;
 
 /* Index order = the rolling.csv columns after "step" (mcmc_eap_chain.jl:259). */
@@ -116,6 +118,8 @@ int eap_run_many(const eap_params *P, uint64_t id0, int64_t nchains, int nthread
 /* Building blocks exported for hand-computable tests. */
 void eap_dipole(const eap_params *P, double cphi, double sphi, double cth, double sth,
                 double mu_out[3]);                                  /* dipole_response.jl:7-29 */
+/* UCutoff: pairs with |r|^2 > rc^2 contribute 0 (inc/eap_chain.jl:171-192) */
+double eap_pair_energy_cutoff(int64_t n, const double *xs, const double *mus, double rc);
 double eap_pair_energy(int64_t n, const double *xs /*3xn col-major*/,
                        const double *mus /*3xn*/, int ising);       /* eap_chain.jl:196-228 */
 double eap_chain_energy(const eap_params *P, const double *phi, const double *theta,

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpstat.so")
 
 DIELECTRIC, POLAR = 0, 1
-NONINTERACTING, INTERACTING, ISING = 0, 1, 2
+NONINTERACTING, INTERACTING, ISING, CUTOFF = 0, 1, 2, 3
 F32, F64, Q16 = 0, 1, 2
 RNG_MWC64X, RNG_XOSHIRO128PP = 0, 1
 NOBS = 16
@@ -45,7 +45,7 @@ class Params(C.Structure):
                 ("chain_type", "energy_type", "do_flips", "umbrella", "precision", "device", "rng", "move_set")] + \
                [(k, C.c_double) for k in
                 ("bend_mod", "bend_angle", "cluster_prob", "x0_phi", "x0_theta", "dx0_phi", "dx0_theta")] + \
-               [("use_x0", C.c_int32), ("reserved", C.c_int32)]
+               [("use_x0", C.c_int32), ("reserved", C.c_int32), ("cutoff_radius", C.c_double)]
 
 
 class Summary(C.Structure):

@@ -67,6 +67,9 @@ struct pstat_handle {
 
 namespace {
 
+// energies whose every step needs all n(n-1)/2 pairs: one chain per wavefront
+bool all_pairs(int energy_type) { return energy_type == PSTAT_INTERACTING || energy_type == PSTAT_CUTOFF; }
+
 int alloc(pstat_handle *h, void **p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) return fail(PSTAT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -82,14 +85,17 @@ int validate(const pstat_params *c, int ncases) {
   if (b.num_chains < 1) return fail(PSTAT_ERR_INVALID_ARG, "num-chains must be >= 1");
   if (b.chain_type != PSTAT_DIELECTRIC && b.chain_type != PSTAT_POLAR)
     return fail(PSTAT_ERR_INVALID_ARG, "chain-type is not understood.");       // eap_chain.jl:86
-  if (b.energy_type < PSTAT_NONINTERACTING || b.energy_type > PSTAT_ISING)
+  if (b.energy_type < PSTAT_NONINTERACTING || b.energy_type > PSTAT_CUTOFF)
     return fail(PSTAT_ERR_INVALID_ARG, "energy-type is not understood.");      // eap_chain.jl:104
-  if (b.energy_type == PSTAT_INTERACTING && b.n > 256)
+  if (b.energy_type == PSTAT_CUTOFF && b.move_set != PSTAT_MOVES_CLUSTER)
+    return fail(PSTAT_ERR_INVALID_ARG, "energy-type 'cutoff' belongs to the clustering main (mcmc_eap_chain.jl has "
+                "no --cutoff-radius)");
+  if (all_pairs(b.energy_type) && b.n > 256)
     return fail(PSTAT_ERR_UNSUPPORTED, "energy-type 'interacting' runs one chain per 64-lane wavefront with "
                 "up to 4 monomers per lane: num-monomers must be <= 256 (got %lld)", (long long)b.n);
   if (b.precision != PSTAT_F32 && b.precision != PSTAT_F64 && b.precision != PSTAT_Q16)
     return fail(PSTAT_ERR_INVALID_ARG, "precision must be PSTAT_F32, PSTAT_F64 or PSTAT_Q16");
-  if (b.precision == PSTAT_Q16 && b.energy_type == PSTAT_INTERACTING)
+  if (b.precision == PSTAT_Q16 && all_pairs(b.energy_type))
     return fail(PSTAT_ERR_UNSUPPORTED, "the lattice state (PSTAT_Q16) is not implemented for energy-type 'interacting'");
   if (b.rng != PSTAT_RNG_MWC64X && b.rng != PSTAT_RNG_XOSHIRO128PP)
     return fail(PSTAT_ERR_INVALID_ARG, "rng must be PSTAT_RNG_MWC64X or PSTAT_RNG_XOSHIRO128PP");
@@ -97,8 +103,6 @@ int validate(const pstat_params *c, int ncases) {
   if (b.move_set != PSTAT_MOVES_SINGLE && b.move_set != PSTAT_MOVES_CLUSTER)
     return fail(PSTAT_ERR_INVALID_ARG, "move_set must be PSTAT_MOVES_SINGLE or PSTAT_MOVES_CLUSTER");
   if (b.move_set == PSTAT_MOVES_CLUSTER) {
-    if (b.energy_type == PSTAT_INTERACTING)
-      return fail(PSTAT_ERR_UNSUPPORTED, "cluster moves are implemented for energy-type noninteracting and Ising");
     if (b.precision == PSTAT_Q16)
       return fail(PSTAT_ERR_UNSUPPORTED, "cluster moves are not implemented for the lattice state (PSTAT_Q16)");
     if (b.do_flips) return fail(PSTAT_ERR_INVALID_ARG, "mcmc_clustering_eap_chain.jl has no --do-flips");
@@ -118,6 +122,8 @@ int validate(const pstat_params *c, int ncases) {
         !std::isfinite(p.Fz) || !std::isfinite(p.Fx) || !std::isfinite(p.b) || !std::isfinite(p.bend_mod) ||
         !std::isfinite(p.bend_angle))
       return fail(PSTAT_ERR_INVALID_ARG, "non-finite physics parameter (case %d)", i);
+    if (b.energy_type == PSTAT_CUTOFF && !(p.cutoff_radius > 0.0))
+      return fail(PSTAT_ERR_INVALID_ARG, "cutoff-radius must be > 0 (case %d)", i);
     if (!(p.cluster_prob >= 0.0 && p.cluster_prob <= 1.0) && b.move_set == PSTAT_MOVES_CLUSTER)
       return fail(PSTAT_ERR_INVALID_ARG, "cluster-prob must be in [0, 1] (case %d)", i);
     if (b.move_set == PSTAT_MOVES_SINGLE && p.bend_mod != 0.0)
@@ -200,6 +206,7 @@ void pstat_default_params(pstat_params *p) {
   p->move_set = PSTAT_MOVES_SINGLE;
   p->bend_mod = 0.0; p->bend_angle = 0.0; p->cluster_prob = 0.5;
   p->use_x0 = 0; p->x0_phi = 0.0; p->x0_theta = 0.0; p->dx0_phi = 2 * M_PI; p->dx0_theta = 1e-1;
+  p->cutoff_radius = 7.5;
 }
 
 int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_handle **out) {
@@ -221,14 +228,14 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   for (int i = 0; i < ncases; ++i) {
     const pstat_params &p = cases[i];
     h->cases.push_back({p.E0, p.K1, p.K2, p.mu, p.kT, p.Fz, p.Fx, p.b, p.seed, p.chain_id0,
-                        p.bend_mod, p.bend_angle, p.cluster_prob});
+                        p.bend_mod, p.bend_angle, p.cluster_prob, p.cutoff_radius});
   }
   bool any_fx = false;
   for (auto &c : h->cases) any_fx = any_fx || c.Fx != 0.0;
   h->cfg = {h->base.precision, h->base.chain_type, h->base.energy_type, h->base.do_flips ? 1 : 0,
             h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, 0, h->base.rng, h->base.move_set};
 
-  const bool inter = h->base.energy_type == PSTAT_INTERACTING;
+  const bool inter = all_pairs(h->base.energy_type);
   int lanes = inter ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
   if (lanes == 0) {
     delete h;
@@ -327,7 +334,10 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_HIP(launch_init(h->cfg, h->args, h->S, h->d_cases, h->base.phi_step, h->base.theta_step, io, h->stream));
   if (inter) {  // a zero-step launch derives r, p, U (with the pair energy) from the fresh angles
     h->args.nsteps = 0; h->args.step0 = 0;
-    CREATE_HIP(launch_interacting(h->cfg, h->args, h->S, h->d_cases, 0, h->stream));
+    if (h->cfg.move_set == PSTAT_MOVES_CLUSTER)
+      CREATE_HIP(launch_cluster_wave(h->cfg, h->args, h->S, h->d_cases, h->stream));
+    else
+      CREATE_HIP(launch_interacting(h->cfg, h->args, h->S, h->d_cases, 0, h->stream));
   }
   CREATE_HIP(hipStreamSynchronize(h->stream));  // h->cases must outlive the copy; also surfaces faults here
   if (!inter) {
@@ -374,12 +384,15 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
   int rc = set_device(h);
   if (rc) return rc;
   const int64_t max_launch = 1ll << 30;  // per-launch step counters are 32-bit
-  if (h->base.energy_type == PSTAT_INTERACTING) {
+  if (all_pairs(h->base.energy_type)) {
     while (nsteps > 0) {
       const int64_t len = nsteps < max_launch ? nsteps : max_launch;
       h->args.nsteps = len;
       h->args.step0 = h->step_in_init;
-      HIP_TRY(launch_interacting(h->cfg, h->args, h->S, h->d_cases, 0, h->stream));
+      if (h->cfg.move_set == PSTAT_MOVES_CLUSTER)
+        HIP_TRY(launch_cluster_wave(h->cfg, h->args, h->S, h->d_cases, h->stream));
+      else
+        HIP_TRY(launch_interacting(h->cfg, h->args, h->S, h->d_cases, 0, h->stream));
       h->step_in_init += len;
       h->steps_recorded += len;
       nsteps -= len;
@@ -690,13 +703,15 @@ int pstat_launch_info_get(pstat_handle *h, pstat_launch_info *out) {
   std::memset(out, 0, sizeof *out);
   int lds = 0, bpc = 0;
   const char *name = "";
-  if (h->base.energy_type == PSTAT_INTERACTING) HIP_TRY(interacting_kernel_info(h->cfg, h->base.n, &bpc, &name));
-  else HIP_TRY(kernel_info(h->cfg, h->args, &lds, &bpc, &name));
+  if (all_pairs(h->base.energy_type)) {
+    if (h->cfg.move_set == PSTAT_MOVES_CLUSTER) HIP_TRY(cluster_wave_kernel_info(h->cfg, h->base.n, &bpc, &name));
+    else HIP_TRY(interacting_kernel_info(h->cfg, h->base.n, &bpc, &name));
+  } else HIP_TRY(kernel_info(h->cfg, h->args, &lds, &bpc, &name));
   std::snprintf(out->kernel, sizeof out->kernel, "%s", name);
   out->lds_bytes = lds;
   out->threads_per_block = 64;
   out->lanes_per_block = h->args.lanes;
-  out->blocks = h->base.energy_type == PSTAT_INTERACTING ? h->S.C : h->args.blocks_per_case * h->ncases;
+  out->blocks = all_pairs(h->base.energy_type) ? h->S.C : h->args.blocks_per_case * h->ncases;
   out->blocks_per_cu = bpc;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));

@@ -1,0 +1,410 @@
+// pstat_cluster_wave.hip -- the step of mcmc_clustering_eap_chain.jl:268-311 for the energies that need
+// every pair: --energy-type interacting (U_interaction, inc/eap_chain.jl:196-211) and cutoff (UCutoff,
+// :165-192).
+//
+// Mapping is the interacting kernel's (pstat_interacting.hip): ONE CHAIN PER WAVEFRONT, lane l owns M
+// consecutive monomers, chain-level quantities are wave-uniform, the n(n-1)/2 pair terms of a
+// configuration are met through a 128-entry LDS ring at compile-time offsets.  One chain per wave also
+// makes the cluster move cheap to express: growth is a wave-uniform loop (no lane divergence at all),
+// members are a contiguous index range, and the proposal is evaluated the way the reference does it --
+// the whole trial configuration is re-derived from its angles (trig, positions by a wave scan, bond
+// angles, u_i + bending, r, p, log sin) and its pair energy summed afresh, so sin(theta) after a
+// reflection is the recomputed one and the reference's corner cases (theta = fl(pi) -> 0) need no
+// special handling.
+//
+// Reference behaviour kept: the acceptor caches log(pi) + log(alpha) (`lag`); with energy-type cutoff
+// the energy functor returns the truncated pair sum ALONE (inc/eap_chain.jl:171-192: no sum(us), no
+// -F.r), so neither the field nor the force enters U there.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include <type_traits>
+
+#include "../../include/pstat.h"
+#include "pstat_device.h"
+#include "pstat_math.h"
+#include "pstat_wave.h"
+
+namespace pstat {
+
+namespace {
+
+__device__ __forceinline__ float cw_acos(float x) { return acosf(x); }
+__device__ __forceinline__ double cw_acos(double x) { return acos(x); }
+__device__ __forceinline__ float cw_log(float x) { return __logf(x); }
+__device__ __forceinline__ double cw_log(double x) { return log(x); }
+
+template <typename R, int M>
+struct Cfg {  // one configuration of the chain, M monomers per lane, and its chain totals
+  R th[M], ph[M], st[M], nx[M], ny[M], nz[M], mx[M], my[M], mz[M], xx[M], xy[M], xz[M];
+  R rx, ry, rz, px, py, pz, usum, psisum, c2sum, upair, U;
+};
+
+template <typename R, typename G, int CT, int M>
+__global__ __launch_bounds__(64) void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
+                                                          int umb, int cutoff) {
+  using AG = Ang<R>;
+  using R4 = typename std::conditional<sizeof(R) == 4, float4, double4>::type;
+  using R2 = typename Vec2<R>::type;
+  __shared__ R4 ringA[128 * M];   // (x, y, z, mu_x) of monomer e mod 64M at entry e
+  __shared__ R2 ringB[128 * M];   // (mu_y, mu_z)
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  const int64_t C = S.C;
+  const int n = (int)A.n;
+  const CaseConst cc = cases[c / A.chains_per_case];
+  const R Fz = (R)cc.Fz, Fx = (R)cc.Fx, b = (R)cc.b, kT = (R)cc.kT;
+  const R a_or_mu = (CT == PSTAT_DIELECTRIC) ? (R)((cc.K1 - cc.K2) * cc.E0) : (R)cc.mu;
+  const R k2e = (R)(cc.K2 * cc.E0);
+  const R mhalfE0 = (R)(-0.5 * cc.E0);
+  const R khalf = (R)(cc.kappa / 2), psi0 = (R)cc.psi0, cprob = (R)cc.cluster_prob;
+  // UCutoff(cutoff-radius * mlen): pairs beyond it contribute nothing; +inf = plain U_interaction
+  const R crad2 = cutoff ? (R)((cc.cutoff_radius * cc.b) * (cc.cutoff_radius * cc.b)) : (R)INFINITY;
+
+  bool real[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) real[j] = lane * M + j < n;
+
+  // ---- everything the reference caches in an EAPChain, from the angles (inc/eap_chain.jl:109-134)
+  auto derive = [&](Cfg<R, M> &q) {
+    R tnx = 0, tny = 0, tnz = 0, tmx = 0, tmy = 0, tmz = 0, tc2 = 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      R ct, sp, cp;
+      AG::sc(q.th[j], &q.st[j], &ct);
+      AG::sc(q.ph[j], &sp, &cp);
+      q.nx[j] = real[j] ? cp * q.st[j] : (R)0; q.ny[j] = real[j] ? sp * q.st[j] : (R)0; q.nz[j] = real[j] ? ct : (R)0;
+      dipole<R, CT>(a_or_mu, k2e, q.nx[j], q.ny[j], q.nz[j], q.mx[j], q.my[j], q.mz[j]);
+      if (!real[j]) { q.mx[j] = 0; q.my[j] = 0; q.mz[j] = 0; }
+      tnx += q.nx[j]; tny += q.ny[j]; tnz += q.nz[j];
+      tmx += q.mx[j]; tmy += q.my[j]; tmz += q.mz[j];
+      tc2 += q.nz[j] * q.nz[j];
+    }
+    R cx = wave_excl_scan<R>(tnx, lane), cy = wave_excl_scan<R>(tny, lane), cz = wave_excl_scan<R>(tnz, lane);
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      cx += q.nx[j]; cy += q.ny[j]; cz += q.nz[j];
+      q.xx[j] = b * (cx - (R)0.5 * q.nx[j]); q.xy[j] = b * (cy - (R)0.5 * q.ny[j]); q.xz[j] = b * (cz - (R)0.5 * q.nz[j]);
+    }
+    // bond angles psi_i = angle(n_i, n_{i+1}) and their bending energy (inc/eap_chain.jl:45-47,54-58);
+    // the successor of my last monomer is the first monomer of the next lane
+    const R fx = __shfl_down(q.nx[0], 1, 64), fy = __shfl_down(q.ny[0], 1, 64), fz = __shfl_down(q.nz[0], 1, 64);
+    R tpsi = 0, tbend = 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const R sx = j + 1 < M ? q.nx[j + 1 < M ? j + 1 : j] : fx;
+      const R sy = j + 1 < M ? q.ny[j + 1 < M ? j + 1 : j] : fy;
+      const R sz = j + 1 < M ? q.nz[j + 1 < M ? j + 1 : j] : fz;
+      const R psi = cw_acos(fmin((R)1, fmax((R)-1, q.nx[j] * sx + q.ny[j] * sy + q.nz[j] * sz)));
+      const bool bonded = lane * M + j + 1 < n;
+      tpsi += bonded ? psi : (R)0;
+      tbend += bonded ? khalf * (psi - psi0) * (psi - psi0) : (R)0;
+    }
+    q.rx = b * wave_allsum<R>(tnx); q.ry = b * wave_allsum<R>(tny); q.rz = b * wave_allsum<R>(tnz);
+    q.px = wave_allsum<R>(tmx); q.py = wave_allsum<R>(tmy); q.pz = wave_allsum<R>(tmz);
+    q.usum = wave_allsum<R>(mhalfE0 * tmz + tbend);
+    q.psisum = wave_allsum<R>(tpsi);
+    q.c2sum = wave_allsum<R>(tc2);
+  };
+
+  // sum over all pairs (within the cutoff) of configuration q
+  auto pair_sum = [&](const Cfg<R, M> &q) -> R {
+    R4 va[M]; R2 vb[M];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const R far = (R)1e6 * (R)(lane * M + j + 1);   // parking position of an unused monomer
+      va[j].x = real[j] ? q.xx[j] : far; va[j].y = real[j] ? q.xy[j] : (R)0; va[j].z = real[j] ? q.xz[j] : (R)0;
+      va[j].w = q.mx[j];
+      vb[j].x = q.my[j]; vb[j].y = q.mz[j];
+      ringA[lane * M + j] = va[j]; ringA[(lane + 64) * M + j] = va[j];
+      ringB[lane * M + j] = vb[j]; ringB[(lane + 64) * M + j] = vb[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const R4 *pa = ringA + lane * M;
+    const R2 *pb = ringB + lane * M;
+    auto term = [&](const R4 &a, const R2 &ab, const R4 &o, const R2 &ob) -> R {
+      const R dx = a.x - o.x, dy = a.y - o.y, dz = a.z - o.z;
+      const R r2 = dx * dx + dy * dy + dz * dz;
+      const R t = pair_fast(dx, dy, dz, a.w, ab.x, ab.y, o.w, ob.x, ob.y);
+      return r2 > crad2 ? (R)0 : t;                  // inc/eap_chain.jl:178-180
+    };
+    R e = 0, e32 = 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+#pragma unroll
+      for (int jp = j + 1; jp < M; ++jp) e += term(va[j], vb[j], va[jp], vb[jp]);
+#pragma unroll 4
+    for (int k = 1; k <= 32; ++k) {
+      R t = 0;
+#pragma unroll
+      for (int jp = 0; jp < M; ++jp) {
+        const R4 qa = pa[(64 - k) * M + jp];
+        const R2 qb = pb[(64 - k) * M + jp];
+#pragma unroll
+        for (int j = 0; j < M; ++j) t += term(va[j], vb[j], qa, qb);
+      }
+      if (k < 32) e += t; else e32 = t;
+    }
+    e = (e + (R)0.5 * e32) * (R)0.0795774715459476679;   // 1/(4 pi)
+    return wave_allsum<R>(e);
+  };
+  // inc/energy.jl:13-16, or UCutoff's functor (pair sum only)
+  auto total_U = [&](Cfg<R, M> &q) {
+    q.upair = pair_sum(q);
+    q.U = cutoff ? q.upair : q.usum + q.upair - (q.rx * Fx + q.rz * Fz);
+  };
+  // per-monomer array value at monomer i (wave-uniform result)
+  auto at = [&](const R (&a)[M], int i) -> R {
+    const int owner = i / M, slot = i % M;
+    R v = 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+      if (slot == j) v = lane_value<R>(a[j], owner);
+    return v;
+  };
+
+  // ---- fill
+  Cfg<R, M> cur;
+  {
+    const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int i = lane * M + j;
+      cur.th[j] = real[j] ? gth[(int64_t)i * C + c] : (R)0;
+      cur.ph[j] = real[j] ? gph[(int64_t)i * C + c] : (R)0;
+    }
+  }
+  G g;
+  {
+    uint32_t w[4];
+    for (int q = 0; q < 4; ++q) w[q] = __builtin_amdgcn_readfirstlane(S.rng[q * C + c]);
+    g.load(w, 1);
+  }
+  double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
+  R phistep = (R)(phistep_d / AG::unit), thstep = (R)(thstep_d / AG::unit);
+  int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
+  int nacc_seg = 0, steps_seg = 0;
+  R lag = (R)S.lag[c];
+  const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
+  const R uref = umb ? (R)S.uref[c] : (R)0;
+  double wnorm = umb ? S.wnorm[c] : 0.0;
+  double sums[NSUMS];
+#pragma unroll
+  for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
+  const R inv_nm1 = n > 1 ? (R)(1.0 / (double)(n - 1)) : (R)0;
+
+  derive(cur);
+  total_U(cur);
+
+  int64_t step = A.step0;
+  int64_t remaining = A.nsteps;
+  const int64_t spa = A.steps_per_adjust;
+  int64_t to_adj = A.adaptive ? spa - (step % spa) : 0;
+  constexpr int FLUSH = 128;
+
+  while (remaining > 0) {
+    int64_t chunk = remaining < FLUSH ? remaining : FLUSH;
+    if (A.adaptive && to_adj < chunk) chunk = to_adj;
+    R acc1[9], acc2[7], accw = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc1[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) acc2[q] = 0;
+
+    for (int k = 0; k < (int)chunk; ++k) {
+      // ---- the single-monomer part of the proposal, mcmc_clustering_eap_chain.jl:269-272
+      const int idx = (int)__umulhi(g.next(), (uint32_t)n);
+      const R dphi = phistep * sym11<R>(g.next());
+      const R dth = thstep * sym11<R>(g.next());
+      const R th0 = at(cur.th, idx), ph0 = at(cur.ph, idx);
+      const R ph1 = AG::wrap(ph0 + dphi);
+      const R th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
+      Cfg<R, M> tr;
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const bool mine = lane * M + j == idx;
+        tr.th[j] = mine ? th1 : cur.th[j];
+        tr.ph[j] = mine ? ph1 : cur.ph[j];
+      }
+
+      // ---- cluster_flip!(trial, idx), inc/eap_chain.jl:269-333 -- wave-uniform
+      R alpha = 1;
+      bool edge = false;
+      if (!(u01<R>(g.next()) <= cprob)) {                                   // :276
+        // theta clamped to exactly 0 and then reflected: the reference's Omega goes -inf then +inf = NaN
+        edge = th1 == (R)0;
+        R st1, ct1, sp1, cp1;
+        AG::sc(th1, &st1, &ct1);
+        AG::sc(ph1, &sp1, &cp1);
+        const R n1x = cp1 * st1, n1y = sp1 * st1, n1z = ct1;
+        int upper = idx, lower = idx;
+        R upper_p = 0, lower_p = 0;
+        R ux = n1x, uy = n1y, uz = n1z, lx = n1x, ly = n1y, lz = n1z;   // n-hat of the two end members
+        bool gu = upper < n - 1, gl = lower > 0;
+        while (gu || gl) {   // rounds: one link above, then one below (the stream contract, pstat_cluster.hip)
+          if (gu) {
+            const R bx = at(cur.nx, upper + 1), by = at(cur.ny, upper + 1), bz = at(cur.nz, upper + 1);
+            upper_p = (1 + (ux * bx + uy * by + uz * bz)) / 2;
+            if (u01<R>(g.next()) <= upper_p) {
+              ++upper; ux = bx; uy = by; uz = bz;
+              if (upper >= n - 1) { upper_p = 0; gu = false; }
+            } else gu = false;
+          }
+          if (gl) {
+            const R bx = at(cur.nx, lower - 1), by = at(cur.ny, lower - 1), bz = at(cur.nz, lower - 1);
+            lower_p = (1 + (lx * bx + ly * by + lz * bz)) / 2;
+            if (u01<R>(g.next()) <= lower_p) {
+              --lower; lx = bx; ly = by; lz = bz;
+              if (lower <= 0) { lower_p = 0; gl = false; }
+            } else gl = false;
+          }
+        }
+        // the boundary links after the reflection n -> (n_x, n_y, -n_z), :318-327
+        R new_upper_p = 0, new_lower_p = 0;
+        if (upper < n - 1) {
+          const R bx = at(cur.nx, upper + 1), by = at(cur.ny, upper + 1), bz = at(cur.nz, upper + 1);
+          new_upper_p = (1 + (ux * bx + uy * by + -uz * bz)) / 2;
+        }
+        if (lower > 0) {
+          const R bx = at(cur.nx, lower - 1), by = at(cur.ny, lower - 1), bz = at(cur.nz, lower - 1);
+          new_lower_p = (1 + (lx * bx + ly * by + -lz * bz)) / 2;
+        }
+        alpha = ((1 - new_upper_p) * (1 - new_lower_p)) / ((1 - upper_p) * (1 - lower_p));   // :328-329
+        // refl_n! on every member, :263-265,314-316
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          const int i = lane * M + j;
+          if (i >= lower && i <= upper) {
+            if constexpr (sizeof(R) == 8) tr.th[j] = fmin(AG::theta_max, fmax((R)0, tr.th[j] + (AG::theta_max - 2 * tr.th[j])));
+            else tr.th[j] = AG::theta_max - tr.th[j];
+          }
+        }
+      }
+      const R eps = u01<R>(g.next());
+
+      // ---- the trial chain, re-derived (what move!/refl_n! do per touched monomer, :230-257) and its energy
+      derive(tr);
+      total_U(tr);
+      R lr = 0;   // Omega(trial) - Omega(current) = sum over touched monomers of log(sin'/sin), :238,117
+#pragma unroll
+      for (int j = 0; j < M; ++j) lr += (real[j] && (tr.th[j] != cur.th[j])) ? cw_log(tr.st[j] / cur.st[j]) : (R)0;
+      const R domega = wave_allsum<R>(lr);
+
+      // ---- Metropolis-Hastings, inc/acceptance.jl:29-39 (NaN from 1/r^3 or log(0/0) => rejected)
+      const R dw = (tr.usum - cur.usum) * wscale;
+      const R dlt = -(tr.U - cur.U) / kT + domega + dw + cw_log(alpha) - lag;
+      bool ok = ((dlt >= 0) || (eps < exp_r(dlt))) && !edge;
+      ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
+      if (ok) {
+        cur = tr;
+        lag = cw_log(alpha);
+        ++nacc_seg;
+      }
+
+      // ---- record! x 10, mcmc_clustering_eap_chain.jl:243-244,310-311
+      const R wgt = umb ? exp_r(-(cur.usum - uref) * wscale) : (R)1;
+      const R obs[9] = {cur.rx, cur.ry, cur.rz, cur.px, cur.py, cur.pz, cur.U, cur.c2sum, cur.psisum * inv_nm1};
+      accw += wgt;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc1[q] = fma_r(wgt, obs[q], acc1[q]);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc2[q] = fma_r(wgt * obs[q], obs[q], acc2[q]);
+    }
+
+    sums[S_R1] += (double)acc1[0]; sums[S_R2] += (double)acc1[1]; sums[S_R3] += (double)acc1[2];
+    sums[S_P1] += (double)acc1[3]; sums[S_P2] += (double)acc1[4]; sums[S_P3] += (double)acc1[5];
+    sums[S_U] += (double)acc1[6]; sums[S_C2] += (double)acc1[7]; sums[S_PSI] += (double)acc1[8];
+    sums[S_R1SQ] += (double)acc2[0]; sums[S_R2SQ] += (double)acc2[1]; sums[S_R3SQ] += (double)acc2[2];
+    sums[S_P1SQ] += (double)acc2[3]; sums[S_P2SQ] += (double)acc2[4]; sums[S_P3SQ] += (double)acc2[5];
+    sums[S_USQ] += (double)acc2[6];
+    wnorm += (double)accw;
+    step += chunk;
+    remaining -= chunk;
+    steps_seg += (int)chunk;
+
+    if (A.adaptive) {  // mcmc_clustering_eap_chain.jl:287-308
+      to_adj -= chunk;
+      if (to_adj == 0) {
+        to_adj = spa;
+        const int nacc = nacc_off + nacc_seg, natt = natt_off + steps_seg;
+        const double ratio = (double)nacc / (double)natt;
+        if (ratio > A.adj_ub && phistep_d != K<double>::pi && thstep_d != K<double>::half_pi) {
+          nacc_off = -nacc_seg; natt_off = -steps_seg;
+          phistep_d = fmin(K<double>::pi, phistep_d * A.adj_scale);
+          thstep_d = fmin(K<double>::half_pi, thstep_d * A.adj_scale);
+        } else if (ratio < A.adj_lb) {
+          nacc_off = -nacc_seg; natt_off = -steps_seg;
+          phistep_d /= A.adj_scale;
+          thstep_d /= A.adj_scale;
+        }
+        phistep = (R)(phistep_d / AG::unit); thstep = (R)(thstep_d / AG::unit);
+      }
+    }
+  }
+
+  // ---- spill
+  {
+    R *wth = (R *)S.ang, *wph = (R *)S.ang + (int64_t)n * C;
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+      if (real[j]) {
+        wth[(int64_t)(lane * M + j) * C + c] = cur.th[j];
+        wph[(int64_t)(lane * M + j) * C + c] = cur.ph[j];
+      }
+  }
+  if (lane == 0) {
+    g.store(S.rng + c, C);
+    S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
+    S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
+    S.nacc_total[c] += nacc_seg;
+    S.obs[OBS_R1 * C + c] = cur.rx; S.obs[OBS_R2 * C + c] = cur.ry; S.obs[OBS_R3 * C + c] = cur.rz;
+    S.obs[OBS_P1 * C + c] = cur.px; S.obs[OBS_P2 * C + c] = cur.py; S.obs[OBS_P3 * C + c] = cur.pz;
+    S.obs[OBS_U * C + c] = cur.U; S.obs[OBS_USUM * C + c] = cur.usum;
+    S.obs[OBS_C2 * C + c] = cur.c2sum; S.obs[OBS_PSI * C + c] = cur.psisum;
+    S.lag[c] = lag;
+    if (umb) S.wnorm[c] = wnorm;
+    for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
+  }
+}
+
+using WaveFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int);
+
+template <typename G, int M>
+WaveFn pick_gm(const LaunchCfg &cfg) {
+  const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
+  if (cfg.precision == PSTAT_F64)
+    return diel ? cluster_wave_kernel<double, G, PSTAT_DIELECTRIC, M> : cluster_wave_kernel<double, G, PSTAT_POLAR, M>;
+  return diel ? cluster_wave_kernel<float, G, PSTAT_DIELECTRIC, M> : cluster_wave_kernel<float, G, PSTAT_POLAR, M>;
+}
+template <typename G>
+WaveFn pick_g(const LaunchCfg &cfg, int64_t n) {
+  if (n <= 64) return pick_gm<G, 1>(cfg);
+  if (n <= 128) return pick_gm<G, 2>(cfg);
+  return pick_gm<G, 4>(cfg);
+}
+WaveFn pick_wave(const LaunchCfg &cfg, int64_t n) {
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_g<Xoshiro128pp>(cfg, n) : pick_g<Mwc64x>(cfg, n);
+}
+
+}  // namespace
+
+hipError_t launch_cluster_wave(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s, const CaseConst *cases,
+                               hipStream_t stream) {
+  WaveFn fn = pick_wave(cfg, a.n);
+  hipLaunchKernelGGL(fn, dim3((unsigned)s.C), dim3(64), 0, stream, a, s, cases, cfg.umbrella,
+                     cfg.energy_type == PSTAT_CUTOFF ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t cluster_wave_kernel_info(const LaunchCfg &cfg, int64_t n, int *blocks_per_cu, const char **name) {
+  WaveFn fn = pick_wave(cfg, n);
+  int nb = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fn, 64, 0);
+  if (e != hipSuccess) return e;
+  if (blocks_per_cu) *blocks_per_cu = nb;
+  if (name) *name = cfg.precision == PSTAT_F64 ? "cluster_wave_kernel<double>" : "cluster_wave_kernel<float>";
+  return hipSuccess;
+}
+
+}  // namespace pstat

@@ -44,6 +44,7 @@ struct CaseConst {      // physics scalars of one case (inc/eap_chain.jl:89-108)
   uint64_t seed, chain_id0;
   double kappa, psi0;     // --bend-mod, --bend-angle (clustering main; 0 in mcmc_eap_chain.jl)
   double cluster_prob;    // --cluster-prob: probability of NOT attempting a cluster flip
+  double cutoff_radius;   // --cutoff-radius in monomer lengths (energy-type cutoff)
 };
 
 struct InitOpts {       // how EAPChain(pargs) draws the first configuration (inc/eap_chain.jl:61-72)
@@ -210,6 +211,10 @@ int choose_lanes(int precision, int64_t n, int energy_type);
 // --energy-type interacting: one chain per wavefront (pstat_interacting.hip), n <= 256
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                               const CaseConst *cases, int reinit_mode, hipStream_t stream);
+// clustering main with the all-pairs energies (interacting, cutoff): pstat_cluster_wave.hip
+hipError_t launch_cluster_wave(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s, const CaseConst *cases,
+                               hipStream_t stream);
+hipError_t cluster_wave_kernel_info(const LaunchCfg &cfg, int64_t n, int *blocks_per_cu, const char **name);
 hipError_t interacting_kernel_info(const LaunchCfg &cfg, int64_t n, int *blocks_per_cu, const char **name);
 
 }  // namespace pstat

@@ -10,8 +10,8 @@ note they differ from mcmc_eap_chain.jl: energy-type defaults to Ising, step-adj
 num-steps to 1e6, and there is a 5-rung burn-in ladder by default).  Added: --num-chains, --seed,
 --devices, --precision, --rng.
 
-Not on the device (the call fails with the reason): --energy-type interacting | cutoff, an --x0 of
-length 2 n (per-monomer start angles).
+All four energy types run on the device (interacting and cutoff: one chain per wavefront, n <= 256).
+Not on the device (the call fails with the reason): an --x0 of length 2 n (per-monomer start angles).
 """
 from __future__ import annotations
 
@@ -122,10 +122,8 @@ def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int)
     ct = {"dielectric": _lib.DIELECTRIC, "polar": _lib.POLAR}.get(pargs["chain-type"])
     if ct is None:
         raise ReferenceError_("chain-type is not understood.")                       # inc/eap_chain.jl:86
-    if pargs["energy-type"] in ("interacting", "cutoff"):
-        raise _lib.PstatError(-4, "option not supported on the device path",
-                              f"energy-type '{pargs['energy-type']}' with cluster moves has no device implementation")
-    et = {"noninteracting": _lib.NONINTERACTING, "Ising": _lib.ISING}.get(pargs["energy-type"])
+    et = {"noninteracting": _lib.NONINTERACTING, "Ising": _lib.ISING, "interacting": _lib.INTERACTING,
+          "cutoff": _lib.CUTOFF}.get(pargs["energy-type"])
     if et is None:
         raise ReferenceError_("energy-type is not understood.")                      # inc/eap_chain.jl:104
     prec = {"f32": _lib.F32, "f64": _lib.F64}.get(pargs["precision"])
@@ -156,7 +154,7 @@ def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int)
         seed=pargs["seed"], chain_id0=chain_id0, chain_type=ct, energy_type=et,
         umbrella=1 if pargs["umbrella-sampling"] else 0, precision=prec, device=device, rng=rng,
         move_set=_lib.MOVES_CLUSTER, bend_mod=pargs["bend-mod"], bend_angle=pargs["bend-angle"],
-        cluster_prob=pargs["cluster-prob"], **x0kw)
+        cluster_prob=pargs["cluster-prob"], cutoff_radius=pargs["cutoff-radius"], **x0kw)
 
 
 def traj_header(n: int) -> str:

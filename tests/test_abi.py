@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(ps):
     for n in names:
         assert hasattr(lib, n), f"libpstat.so does not export {n}"
     assert sorted(ps._lib.SYMBOLS) == names, "binding's symbol list is out of date"
-    assert lib.pstat_abi_version() == 3
+    assert lib.pstat_abi_version() == 4
 
 
 def test_struct_layout_matches_header(ps, tmp_path):
@@ -40,14 +40,15 @@ def test_struct_layout_matches_header(ps, tmp_path):
                    'offsetof(pstat_params, seed), offsetof(pstat_params, rng), sizeof(pstat_summary),'
                    'offsetof(pstat_summary, num_chains), sizeof(pstat_launch_info));'
                    'printf("%zu %zu %zu %zu\\n", offsetof(pstat_params, move_set), offsetof(pstat_params, bend_mod),'
-                   'offsetof(pstat_params, use_x0), offsetof(pstat_summary, extra_avg));return 0;}\n')
+                   'offsetof(pstat_params, use_x0), offsetof(pstat_summary, extra_avg));'
+                   'printf("%zu\\n", offsetof(pstat_params, cutoff_radius));return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     P, S, LI = ps._lib.Params, ps._lib.Summary, ps._lib.LaunchInfo
     assert got == [C.sizeof(P), P.steps_per_adjust.offset, P.seed.offset, P.rng.offset, C.sizeof(S),
                    S.num_chains.offset, C.sizeof(LI), P.move_set.offset, P.bend_mod.offset, P.use_x0.offset,
-                   S.extra_avg.offset]
+                   S.extra_avg.offset, P.cutoff_radius.offset]
 
 
 def test_defaults_are_the_references(ps):
@@ -61,7 +62,7 @@ def test_defaults_are_the_references(ps):
     assert p.rng == ps.RNG_MWC64X and p.precision == ps.F32 and p.reserved == 0
     # mcmc_clustering_eap_chain.jl:36-43,87-90,146-148
     assert p.move_set == ps.MOVES_SINGLE and (p.bend_mod, p.bend_angle, p.cluster_prob) == (0.0, 0.0, 0.5)
-    assert p.use_x0 == 0 and (p.dx0_phi, p.dx0_theta) == (2 * math.pi, 0.1)
+    assert p.use_x0 == 0 and (p.dx0_phi, p.dx0_theta) == (2 * math.pi, 0.1) and p.cutoff_radius == 7.5
 
 
 def test_strerror_and_invalid_arguments(ps):
@@ -72,7 +73,8 @@ def test_strerror_and_invalid_arguments(ps):
     for bad in (dict(n=0), dict(kT=-1.0), dict(chain_type=7), dict(energy_type=9), dict(num_chains=0),
                 dict(precision=5), dict(phi_step=0.0), dict(rng=3), dict(reserved=1), dict(move_set=2),
                 dict(move_set=1, cluster_prob=1.5), dict(move_set=1, do_flips=1), dict(bend_mod=1.0),
-                dict(use_x0=1, x0_theta=float("nan"))):
+                dict(use_x0=1, x0_theta=float("nan")), dict(energy_type=3),
+                dict(energy_type=3, move_set=1, cutoff_radius=0.0)):
         p = ps.default_params(**bad)
         rc = lib.pstat_create(C.byref(p), 1, None, C.byref(h))
         assert rc == -1, (bad, rc)

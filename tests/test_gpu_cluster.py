@@ -115,6 +115,42 @@ def test_f64_bit_parity_cluster_umbrella(ps, oracle):
                 bend_mod=0.4, bend_angle=0.2, cluster_prob=0.5, steps_per_adjust=500)
 
 
+@pytest.mark.parametrize("n,kw", [
+    (20, dict(energy_type=1, E0=1.0, K1=1.0, K2=0.1, Fz=0.4, Fx=0.2, bend_mod=0.3, bend_angle=0.2)),   # M = 1
+    (23, dict(energy_type=1, E0=0.8, mu=0.3, chain_type=1, Fz=0.5, rng=1)),
+    (70, dict(energy_type=1, E0=1.0, K1=0.8, K2=0.0, Fz=0.3, bend_mod=0.2)),                          # M = 2
+    (130, dict(energy_type=1, E0=1.0, K1=0.5, K2=0.0, Fz=0.3)),                                      # M = 4
+    (20, dict(energy_type=3, cutoff_radius=2.5, E0=1.0, K1=0.6, K2=0.1, Fz=0.4, bend_mod=0.3)),
+    (70, dict(energy_type=3, cutoff_radius=7.5, E0=1.0, K1=0.6, K2=0.0, Fz=0.4, umbrella=1)),
+])
+def test_f64_bit_parity_cluster_all_pairs(ps, oracle, n, kw):
+    """interacting / cutoff energies with cluster moves: the one-chain-per-wavefront kernel against the
+    oracle's literal restatement (short runs: these energies share the 1/r^3 collapse of the Ising one)."""
+    _bit_parity(ps, oracle, 700, 5, n=n, kT=1.0, seed=51, cluster_prob=0.5, steps_per_adjust=200, **kw)
+
+
+def test_f64_all_pairs_burn_in_ladder(ps, oracle):
+    _bit_parity(ps, oracle, 500, 4, burn_sched=(10.0, 1.0), burn_in=300, n=24, E0=1.0, K1=0.7, Fz=0.4, kT=0.9,
+                seed=52, energy_type=1, cluster_prob=0.4, steps_per_adjust=150)
+
+
+def test_f32_all_pairs_cluster_statistics(ps, oracle):
+    kw = dict(n=16, E0=1.0, K1=0.5, K2=0.05, Fz=0.6, kT=1.0, seed=53, bend_mod=0.3, cluster_prob=0.5, energy_type=1)
+    nsteps, burn = 3000, 1000
+    op, pp = _pair(ps, nsteps, 2048, ps.F32, (1.0,), burn, **kw)
+    with ps.Ensemble(pp) as e:
+        _run_gpu(e, pp, nsteps, (1.0,), burn)
+        s = e.summary()
+        assert b"cluster_wave_kernel" in e.launch_info().kernel
+    gm, gs = np.array(s.avg), np.array(s.stderr)
+    sums, norm, nacc = oracle.run_many(op, 1 << 20, 512, nthreads=8, mode="cluster")
+    om, os_ = pooled(sums, norm)
+    # U^2 is dominated by rare close approaches (1/r^3): compare everything else
+    keep = [i for i, k in enumerate(oracle.OBS_NAMES) if k != "Usq"]
+    z = ((gm - om) / np.sqrt(gs ** 2 + os_ ** 2 + 1e-300))[keep]
+    assert np.all(np.abs(z) < 4.5), (z, gm, om)
+
+
 @pytest.mark.parametrize("energy_type,K1", [(0, 1.0), (2, 0.2)])
 def test_f32_cluster_statistics(ps, oracle, energy_type, K1):
     kw = dict(n=20, E0=1.0, K1=K1, K2=0.1 * K1, Fz=0.8, kT=1.0, seed=31, bend_mod=0.5, bend_angle=0.3,
@@ -172,9 +208,9 @@ def test_cluster_full_size_properties(ps):
 
 
 def test_cluster_errors(ps):
-    for bad in (dict(energy_type=1), dict(precision=ps.Q16)):
+    for bad in (dict(energy_type=1, n=300), dict(precision=ps.Q16), dict(energy_type=3, precision=ps.Q16)):
         with pytest.raises(ps.PstatError) as ei:
-            ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, n=16, **bad))
+            ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, **{"n": 16, **bad}))
         assert ei.value.code == -4
     with ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, n=16, num_chains=64)) as e:
         with pytest.raises(ps.PstatError):

@@ -83,6 +83,13 @@ def main():
                 res.append(run(ps, torch, f"C6 clustering main n=100 {en} E0=1 K1=0 K2=1 kT=1 [{tag}]",
                                P(n=100, E0=1.0, K1=0.0, K2=1.0, kT=1.0, energy_type=et, num_chains=65536, precision=prec,
                                  seed=6, move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, adj_ub=0.40), 20000 // q))
+            # C7: clustering main with the all-pairs energies (one chain per wavefront)
+            res.append(run(ps, torch, f"C7 clustering main n=100 interacting E0=1 K1=1 Fz=0.5 [{tag}]",
+                           P(n=100, E0=1.0, K1=1.0, Fz=0.5, energy_type=ps.INTERACTING, num_chains=16384, precision=prec,
+                             seed=7, move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, adj_ub=0.40), 4000 // q))
+            res.append(run(ps, torch, f"C7 clustering main n=100 cutoff 7.5 E0=1 K1=1 Fz=0.5 [{tag}]",
+                           P(n=100, E0=1.0, K1=1.0, Fz=0.5, energy_type=ps.CUTOFF, cutoff_radius=7.5, num_chains=16384,
+                             precision=prec, seed=7, move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, adj_ub=0.40), 4000 // q))
     return 0
 
 
