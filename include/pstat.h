@@ -167,6 +167,9 @@ int pstat_reinit(pstat_handle *h, int32_t force_init);
  * depend on kT). */
 int pstat_reset_averages(pstat_handle *h);
 int pstat_set_kT(pstat_handle *h, int32_t icase, double kT);
+/* kT of every case <- (the kT it was created with) * mult: one rung of the burn-in ladder for a whole
+ * sweep grid (mcmc_clustering_eap_chain.jl:368,379: burnargs["kT"] = kT_base * kT_mult). */
+int pstat_scale_kT(pstat_handle *h, double mult);
 /* What a fresh call of the reference's mcmc(nsteps, pargs, chain) resets besides the averagers
  * (mcmc_clustering_eap_chain.jl:172-181,263-266): step sizes back to --phi-step/--theta-step, the
  * adaptation counters, the acceptor's cache, the in-run step counter.  The chains are kept. */

@@ -47,6 +47,7 @@ struct Buffer {
 struct pstat_handle {
   pstat_params base{};              // case 0's parameters (shared, non-physics fields)
   std::vector<CaseConst> cases;     // host copy
+  std::vector<double> kT0;          // kT each case was created with (pstat_scale_kT)
   CaseConst *d_cases = nullptr;
   int ncases = 0;
   int device = 0;
@@ -229,6 +230,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
     const pstat_params &p = cases[i];
     h->cases.push_back({p.E0, p.K1, p.K2, p.mu, p.kT, p.Fz, p.Fx, p.b, p.seed, p.chain_id0,
                         p.bend_mod, p.bend_angle, p.cluster_prob, p.cutoff_radius});
+    h->kT0.push_back(p.kT);
   }
   bool any_fx = false;
   for (auto &c : h->cases) any_fx = any_fx || c.Fx != 0.0;
@@ -496,6 +498,17 @@ int pstat_set_kT(pstat_handle *h, int32_t icase, double kT) {
   HIP_TRY(hipStreamSynchronize(h->stream));   // the host copy of the constants is re-uploaded
   for (int i = 0; i < h->ncases; ++i)
     if (icase < 0 || icase == i) h->cases[(size_t)i].kT = kT;
+  HIP_TRY(hipMemcpy(h->d_cases, h->cases.data(), sizeof(CaseConst) * (size_t)h->ncases, hipMemcpyHostToDevice));
+  return PSTAT_OK;
+}
+
+int pstat_scale_kT(pstat_handle *h, double mult) {
+  if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
+  if (!(mult > 0) || !std::isfinite(mult)) return fail(PSTAT_ERR_INVALID_ARG, "kT multiplier must be > 0");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < h->ncases; ++i) h->cases[(size_t)i].kT = h->kT0[(size_t)i] * mult;
   HIP_TRY(hipMemcpy(h->d_cases, h->cases.data(), sizeof(CaseConst) * (size_t)h->ncases, hipMemcpyHostToDevice));
   return PSTAT_OK;
 }

@@ -66,6 +66,10 @@ class Ensemble:
     def set_kT(self, kT: float, icase: int = -1):
         check(self._L.pstat_set_kT(self._h, icase, float(kT)))
 
+    def scale_kT(self, mult: float):
+        """kT of every case <- its creation-time kT * mult (one rung of the burn-in ladder for a grid)."""
+        check(self._L.pstat_scale_kT(self._h, float(mult)))
+
     # --- read-outs
     def reduce_into(self, dev_ptr: int, icase: int = -1):
         """Device-side reduction into a caller-owned device buffer of NRED doubles (async)."""

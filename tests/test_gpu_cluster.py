@@ -215,3 +215,20 @@ def test_cluster_errors(ps):
     with ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, n=16, num_chains=64)) as e:
         with pytest.raises(ps.PstatError):
             e.reinit(True)
+
+
+def test_scale_kT_is_a_ladder_rung_for_every_case(ps):
+    """pstat_scale_kT: kT_i <- kT0_i * mult for all cases of a sweep grid at once (a phase scan's ladder)."""
+    def cases(mult):
+        return [ps.default_params(n=12, E0=1.0, Fz=0.3, kT=kT * mult, num_chains=64, seed=61 + i, precision=ps.F64,
+                                  move_set=ps.MOVES_CLUSTER, cluster_prob=0.5) for i, kT in enumerate((0.5, 2.0))]
+    with ps.Ensemble(cases(1.0)) as a, ps.Ensemble(cases(10.0)) as b:
+        a.scale_kT(10.0)
+        a.advance(800); b.advance(800)
+        a.sync(); b.sync()
+        for c in (0, 63, 64, 127):
+            ga, gb = a.chain_state(c), b.chain_state(c)
+            assert np.array_equal(ga["theta"], gb["theta"]) and ga["nacc_total"] == gb["nacc_total"]
+        a.scale_kT(1.0)
+        with pytest.raises(ps.PstatError):
+            a.scale_kT(0.0)

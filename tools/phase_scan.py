@@ -6,6 +6,8 @@ the only exchange is one all-reduce(SUM) of the [points x 39] reduction tensor (
 with torch.distributed.run, nothing at all for one GPU).
 
     python tools/phase_scan.py --chains 128 --steps 50000 --burn-in 20000 --energy Ising --out scan.csv
+    python tools/phase_scan.py --main clustering --burn-schedule "1000,100,10,2,1" ...   # what the reference's
+        # run/K1_E0-kT-phase.jl:45 launches per grid point: mcmc_clustering_eap_chain.jl with its annealed ladder
     python -m torch.distributed.run --nproc-per-node 8 tools/phase_scan.py ...
 """
 import argparse
@@ -24,6 +26,11 @@ def main():
     ap.add_argument("--burn-in", type=int, default=20000)
     ap.add_argument("--energy", choices=["noninteracting", "Ising"], default="Ising")
     ap.add_argument("--precision", choices=["f32", "f64", "q16"], default="f32")
+    ap.add_argument("--main", choices=["fixed-force", "clustering"], default="fixed-force",
+                    help="which main's step: mcmc_eap_chain.jl or mcmc_clustering_eap_chain.jl (cluster flips)")
+    ap.add_argument("--burn-schedule", default="1", help="kT multipliers of the burn-in ladder, comma-separated")
+    ap.add_argument("--bend-mod", type=float, default=0.0)
+    ap.add_argument("--cluster-prob", type=float, default=0.5)
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -43,15 +50,27 @@ def main():
     grid = [(0.2 * i, 10.0 ** (-2 + 0.2 * j)) for i in range(26) for j in range(21)]
     cases = [ps.default_params(n=args.n, E0=E0, kT=kT, K1=1.0, K2=0.0, b=1.0, num_chains=args.chains,
                                chain_id0=rank * args.chains, seed=20260501 + k, precision=prec,
-                               energy_type=en, device=local)
+                               energy_type=en, device=local,
+                               **(dict(move_set=ps.MOVES_CLUSTER, bend_mod=args.bend_mod, cluster_prob=args.cluster_prob,
+                                       adj_ub=0.40) if args.main == "clustering" else {}))
              for k, (E0, kT) in enumerate(grid)]
     stream = torch.cuda.Stream()
     red = torch.zeros(len(grid), ps.NRED, dtype=torch.float64, device="cuda")
     with torch.cuda.stream(stream):
         e = ps.Ensemble(cases, stream=stream.cuda_stream)
         t0 = time.perf_counter()
+        ladder = [float(x) for x in args.burn_schedule.split(",") if x.strip()]
+        rungs = 0
         if args.burn_in > 0:
-            e.advance(args.burn_in)
+            for mult in ladder:             # every rung is a fresh mcmc() call in the clustering main
+                e.scale_kT(mult)
+                if args.main == "clustering":
+                    e.reset_sampler()
+                e.advance(args.burn_in)
+                rungs += 1
+            e.scale_kT(1.0)
+            if args.main == "clustering":
+                e.reset_sampler()
             e.reset_averages()
         e.advance(args.steps)
         for k in range(len(grid)):
@@ -72,8 +91,8 @@ def main():
             open(args.out, "w").write(text)
         else:
             sys.stdout.write(text[:2000] + ("...\n" if len(text) > 2000 else ""))
-        upd = world * len(grid) * args.chains * (args.steps + args.burn_in)
-        print(f"# {len(grid)} grid points x {world * args.chains} chains, n={args.n}, {args.energy}, {args.precision}: "
+        upd = world * len(grid) * args.chains * (args.steps + rungs * args.burn_in)
+        print(f"# {len(grid)} grid points x {world * args.chains} chains, n={args.n}, {args.main} main, {args.energy}, {args.precision}: "
               f"{wall:.3f} s wall, {upd / wall:.3e} attempted updates/s", file=sys.stderr)
     e.close()
     if world > 1:
