@@ -425,54 +425,15 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
   for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
 }
 
-// the sweep kernel's persistent job loop (pstat_kernels.hip) around run_cluster_segment
+// the persistent (block, segment) job loop of pstat_device.h around run_cluster_segment
 template <typename R, typename G, int CT, int EN>
 __global__ __launch_bounds__(64) void cluster_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
                                                      int umbrella, int *__restrict__ queue) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
-  const int nblocks = (int)(A.blocks_per_case * A.ncases);
-  const int njobs = nblocks * A.nseg;
-  int *head = queue, *error = queue + 1, *done = queue + 2;
-  bool failed = false;
-  while (!failed) {
-    int job = 0;
-    if (lane == 0) job = atomicAdd(head, 1);
-    job = __builtin_amdgcn_readfirstlane(job);
-    if (job >= njobs) break;
-    const int blk = job % nblocks, seg = job / nblocks;
-    if (seg > 0) {
-      int spins = 0;
-      for (;;) {
-        const int have = __builtin_amdgcn_readfirstlane(
-            __hip_atomic_load(&done[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (have >= seg) break;
-        if (++spins > A.max_spins) { failed = true; break; }
-        __builtin_amdgcn_s_sleep(64);
-      }
-      if (failed) {
-        if (lane == 0) atomicExch(error, 1 + job);
-        break;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    const int64_t icase = blk / A.blocks_per_case;
-    const int64_t local = (int64_t)(blk % A.blocks_per_case) * A.lanes + lane;
-    const int64_t first = (int64_t)seg * A.seg_len;
-    const int64_t rest = A.nsteps - first;
-    const int64_t len = rest < A.seg_len ? rest : A.seg_len;
-    if (len > 0 && lane < A.lanes && local < A.chains_per_case) {
-      const CaseConst cc = cases[icase];
-      run_cluster_segment<R, G, CT, EN>(A, S, cc, umbrella, smem, lane, icase * A.chains_per_case + local,
-                                        A.step0 + first, len);
-    }
-    if (A.nseg > 1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(&done[blk], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len) {
+    run_cluster_segment<R, G, CT, EN>(A, S, cc, umbrella, smem, lane, chain, first, len);
+  }, cases);
 }
 
 using ClusterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int *);

@@ -481,64 +481,16 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   for (int q = 0; q < NSUMS_BASE; ++q) S.sums[q * C + c] = sums[q];
 }
 
-// Persistent sweep kernel.  A job = (chain block, time segment); jobs are handed out in segment-major
-// order from one atomic counter, so all LDS-limited workgroup slots of the chip stay busy even when
-// the number of chain blocks is not a multiple of the slots (e.g. 1024 blocks on 768 slots at
-// n = 100).  Segment s of a block may start only after segment s-1 of the same block has been
-// spilled: a per-block counter, published with an agent-scope release and awaited with a relaxed
-// poll + one agent-scope acquire (placement-independent; cdna_hip_programming.md Guideline 16).
-// Deadlock-free for any residency: a job's predecessor was handed out earlier, to a workgroup that is
-// running and that itself only ever waits on still earlier jobs.
+// Persistent sweep kernel: run_segment under the (block, segment) job loop of pstat_device.h.
 template <typename R, typename G, int CT, int EN, bool FX, bool RARE, int ST>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
                                                    const CaseConst *__restrict__ cases,
                                                    SweepRare rare, int *__restrict__ queue) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
-  const int nblocks = (int)(A.blocks_per_case * A.ncases);
-  const int njobs = nblocks * A.nseg;
-  int *head = queue, *error = queue + 1, *done = queue + 2;
-  bool failed = false;
-  while (!failed) {
-    int job = 0;
-    if (lane == 0) job = atomicAdd(head, 1);
-    job = __builtin_amdgcn_readfirstlane(job);
-    if (job >= njobs) break;
-    const int blk = job % nblocks, seg = job / nblocks;
-    if (seg > 0) {
-      int spins = 0;
-      for (;;) {
-        const int have = __builtin_amdgcn_readfirstlane(
-            __hip_atomic_load(&done[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (have >= seg) break;
-        if (++spins > A.max_spins) { failed = true; break; }
-        __builtin_amdgcn_s_sleep(64);
-      }
-      if (failed) {  // a predecessor never finished: flag it and stop taking jobs
-        if (lane == 0) atomicExch(error, 1 + job);
-        break;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    const int64_t icase = blk / A.blocks_per_case;
-    const int64_t local = (int64_t)(blk % A.blocks_per_case) * A.lanes + lane;
-    const int64_t first = (int64_t)seg * A.seg_len;
-    const int64_t left = A.nsteps - first;
-    const int64_t len = left < A.seg_len ? left : A.seg_len;
-    // lanes own disjoint LDS columns and never exchange data: idle lanes just skip the body
-    if (len > 0 && lane < A.lanes && local < A.chains_per_case) {
-      const CaseConst cc = cases[icase];
-      run_segment<R, G, CT, EN, FX, RARE, ST>(A, S, cc, rare, smem, lane,
-                                             icase * A.chains_per_case + local, A.step0 + first, len);
-    }
-    if (A.nseg > 1) {
-      // publish: this wave's spill stores are complete and written back before the counter moves
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(&done[blk], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len) {
+    run_segment<R, G, CT, EN, FX, RARE, ST>(A, S, cc, rare, smem, lane, chain, first, len);
+  }, cases);
 }
 
 #ifndef PSTAT_PART
