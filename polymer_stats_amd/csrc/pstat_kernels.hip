@@ -107,14 +107,14 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
 // ------------------------------------------------------------------------------------------ sweep
 
 struct Draw {  // raw words of one step's proposal, mcmc_eap_chain.jl:277-280,287
-  uint32_t idx, cell, wphi, wth, weps, wflip;   // cell = idx * lanes + lane: the LDS slot of the monomer
+  uint32_t idx, cell, wphi, wth, weps, wflip;   // cell = byte offset of the monomer's LDS slot [idx][lane]
 };
 
 template <bool RARE, typename G>
-__device__ __forceinline__ Draw draw_step(G &g, uint32_t n, bool flips, uint32_t lanes, uint32_t lane) {
+__device__ __forceinline__ Draw draw_step(G &g, uint32_t n, bool flips, uint32_t row_bytes, uint32_t lane_bytes) {
   Draw d;
   d.idx = __umulhi(g.next(), n);
-  d.cell = d.idx * lanes + lane;
+  d.cell = __umul24(d.idx, row_bytes) + lane_bytes;   // one v_mad_u32_u24 (idx < 2^24, a row < 2^24 bytes)
   d.wphi = g.next();
   d.wflip = 0;
   if constexpr (RARE) {
@@ -209,8 +209,10 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // step computes; if both steps hit the same monomer and the current one is accepted, the
   // prefetched row is replaced by the freshly accepted angles.
   using P = typename V2<R>::type;   // {old, new}
-  Draw dA = draw_step<RARE>(g, (uint32_t)n, flips, (uint32_t)lanes, (uint32_t)lane), dB = dA;
-  Cell aA = ang[dA.cell], aB = aA;
+  const uint32_t row_bytes = (uint32_t)lanes * (uint32_t)sizeof(Cell), lane_bytes = (uint32_t)lane * (uint32_t)sizeof(Cell);
+  auto slot = [&](uint32_t off) __attribute__((always_inline)) -> Cell & { return *reinterpret_cast<Cell *>(smem + off); };
+  Draw dA = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes), dB = dA;
+  Cell aA = slot(dA.cell), aB = aA;
   R phistep3 = 3 * phistep, thstep3 = 3 * thstep;
   (void)phistep3; (void)thstep3;
   int left = (int)remaining;        // steps still to run in this segment (<= 2^30)
@@ -231,8 +233,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     auto one_step = [&](const Draw &d, const Cell &a0, Draw &dn, Cell &an, const bool more)
         __attribute__((always_inline)) {
       if (more) {
-        dn = draw_step<RARE>(g, (uint32_t)n, flips, (uint32_t)lanes, (uint32_t)lane);
-        an = ang[dn.cell];
+        dn = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes);
+        an = slot(dn.cell);
       }
       // ---- proposal, mcmc_eap_chain.jl:277-280, and trial angles, inc/eap_chain.jl:232-236
       R eps;                        // u in [0,1) (f64) or 1 + u (f32: the -1 is folded into the test)
@@ -270,7 +272,9 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         } else {
           // angle + step * (f - 3) with f in [2,4): the -3*step rides on the base angle
           ph1 = AG::wrap(fma_r(phistep, bits24(d.wphi), ph0 - phistep3));
-          th1 = fmin(AG::theta_max, fmax((R)0, fma_r(thstep, bits24(d.wth), (th0 + flip) - thstep3)));
+          R base = th0;
+          if constexpr (RARE) base = th0 + flip;
+          th1 = fmin(AG::theta_max, fmax((R)0, fma_r(thstep, bits24(d.wth), base - thstep3)));
         }
       }
       R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
@@ -325,9 +329,11 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         }
         dpair = e1 - e0;
       }
+      R dUi = du;   // (x + 0 is not folded under IEEE rules: keep the zero terms out of the arithmetic)
+      if constexpr (EN == PSTAT_ISING) dUi = du + dpair;
       R dU;
-      if constexpr (FX) dU = du + dpair - (Fx * (b * dNxy.x) + Fz * drz);
-      else              dU = du + dpair - (Fz * drz);
+      if constexpr (FX) dU = dUi - (Fx * (b * dNxy.x) + Fz * drz);
+      else              dU = dUi - (Fz * drz);
 
       // ---- Metropolis, inc/acceptance.jl:18-39.  pi ~ exp(-U/kT) * prod sin(theta)
       bool ok;
@@ -349,7 +355,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       Cell a1;
       if constexpr (Q) a1 = ok ? cell1 : a0;
       else { a1.x = ok ? th1 : th0; a1.y = ok ? ph1 : ph0; }
-      ang[d.cell] = a1;
+      slot(d.cell) = a1;
       const R m = ok ? (R)1 : (R)0;
       const P mm = {m, m};
       if constexpr (sizeof(R) == 8) {  // the oracle's update order: r += b*dn, p += dm, U += dU
