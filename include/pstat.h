@@ -212,6 +212,12 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles /* [2n] */,
 
 /* Checkpoint / resume of the full device state (angles, generators, step sizes, counters, running
  * sums).  Call with buf == NULL to get the size.  The reference has no equivalent. */
+/* Start every chain over from a given configuration, as EAPChain(pargs) does with --x0/--dx0
+ * (inc/eap_chain.jl:61-79): x0 holds [phi; theta] (len 2: every monomer) or the interleaved
+ * [phi1, theta1, phi2, theta2, ...] (len 2n); each angle gets + Uniform(0, dx0).  Generators are
+ * re-seeded, so the result is what pstat_create would have produced with that start; averagers,
+ * step sizes and counters are reset.  x0 is host memory, copied before the call returns. */
+int pstat_restart_from_x0(pstat_handle *h, const double *x0, int64_t len, double dx0_phi, double dx0_theta);
 /* The clustering main's two extra averagers for one chain: their running sums and their value in
  * the current configuration (sum cos^2 theta; mean bond angle). */
 int pstat_chain_extras(pstat_handle *h, int64_t chain, double extra_sums[2], double extra_now[2]);

@@ -35,7 +35,8 @@ class EapParams(C.Structure):
                [(k, C.c_double) for k in
                 ("bend_mod", "bend_angle", "cluster_prob", "x0_phi", "x0_theta", "dx0_phi", "dx0_theta")] + \
                [("burn_sched", C.c_double * 8), ("burn_in", C.c_int64),
-                ("burn_nsched", C.c_int32), ("use_x0", C.c_int32), ("cutoff_radius", C.c_double)]
+                ("burn_nsched", C.c_int32), ("use_x0", C.c_int32), ("cutoff_radius", C.c_double),
+                ("x0_vec", C.POINTER(C.c_double)), ("x0_len", C.c_int64)]
 
 
 class EapResult(C.Structure):
@@ -106,6 +107,7 @@ def make_params(**kw) -> EapParams:
              bend_mod=0.0, bend_angle=0.0, cluster_prob=1.0, x0_phi=0.0, x0_theta=0.0,
              dx0_phi=2 * np.pi, dx0_theta=0.1, burn_in=0, burn_nsched=0, use_x0=0, cutoff_radius=7.5)
     sched = list(kw.pop("burn_sched", []))
+    x0_vec = kw.pop("x0_vec", None)
     unknown = set(kw) - set(d)
     if unknown:
         raise KeyError(f"unknown oracle parameter(s): {sorted(unknown)}")
@@ -115,6 +117,11 @@ def make_params(**kw) -> EapParams:
     p = EapParams(**d)
     for i, v in enumerate(sched):
         p.burn_sched[i] = v
+    if x0_vec is not None:       # per-monomer start [phi1, theta1, phi2, theta2, ...]; keep the buffer alive on p
+        p._x0_keep = np.ascontiguousarray(x0_vec, dtype=np.float64)
+        p.x0_vec = p._x0_keep.ctypes.data_as(C.POINTER(C.c_double))
+        p.x0_len = len(p._x0_keep)
+        p.use_x0 = 1
     return p
 
 

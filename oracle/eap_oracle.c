@@ -313,7 +313,10 @@ static void chain_derive(const eap_params *P, chain_t *c) {
 
 /* EAPChain(pargs), eap_chain.jl:60-135: all phi draws, then all theta draws */
 static void chain_random(const eap_params *P, uint32_t rng[5], chain_t *c) {
-  if (P->use_x0) { /* eap_chain.jl:69-72: x0 = [phi; theta] plus Uniform(0, dx0) */
+  if (P->use_x0 && P->x0_vec && P->x0_len == 2 * c->n) { /* eap_chain.jl:73-75: per-monomer start, interleaved */
+    for (int64_t i = 0; i < c->n; ++i) c->phi[i] = P->x0_vec[2 * i] + P->dx0_phi * draw_u(rng);
+    for (int64_t i = 0; i < c->n; ++i) c->th[i] = P->x0_vec[2 * i + 1] + P->dx0_theta * draw_u(rng);
+  } else if (P->use_x0) { /* eap_chain.jl:69-72: x0 = [phi; theta] plus Uniform(0, dx0) */
     for (int64_t i = 0; i < c->n; ++i) c->phi[i] = P->x0_phi + P->dx0_phi * draw_u(rng);
     for (int64_t i = 0; i < c->n; ++i) c->th[i] = P->x0_theta + P->dx0_theta * draw_u(rng);
   } else {

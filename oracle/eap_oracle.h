@@ -56,6 +56,8 @@ typedef struct eap_params {
   int32_t burn_nsched;                  /* number of rungs used */
   int32_t use_x0;
   double cutoff_radius;                 /* --cutoff-radius, in monomer lengths (:48-51; x mlen at inc/eap_chain.jl:102) */
+  const double *x0_vec;                 /* --x0 of length 2n, [phi1, theta1, phi2, theta2, ...] (inc/eap_chain.jl:73-75); */
+  int64_t x0_len;                       /*   used when use_x0 != 0 and x0_len == 2n, else x0_phi/x0_theta */
 } eap_params;
 
 /* Index order = the rolling.csv columns after "step" (mcmc_eap_chain.jl:259). */

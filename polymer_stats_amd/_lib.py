@@ -24,7 +24,7 @@ SYMBOLS = [
     "pstat_abi_version", "pstat_strerror", "pstat_last_error", "pstat_device_count",
     "pstat_default_params", "pstat_create", "pstat_destroy", "pstat_advance", "pstat_sync",
     "pstat_reinit", "pstat_reset_averages", "pstat_set_kT", "pstat_scale_kT", "pstat_reset_sampler", "pstat_reduce_device", "pstat_reduce_host", "pstat_rolling", "pstat_microstate",
-    "pstat_summary_get", "pstat_summary_from_reduction", "pstat_chain_state", "pstat_chain_extras",
+    "pstat_summary_get", "pstat_summary_from_reduction", "pstat_chain_state", "pstat_chain_extras", "pstat_restart_from_x0",
     "pstat_checkpoint", "pstat_restore", "pstat_launch_info_get",
 ]
 
@@ -92,6 +92,7 @@ def load():
     L.pstat_set_kT.argtypes = [vp, i32, C.c_double]
     L.pstat_reset_sampler.argtypes = [vp]
     L.pstat_scale_kT.argtypes = [vp, C.c_double]
+    L.pstat_restart_from_x0.argtypes = [vp, dp, i64, C.c_double, C.c_double]
     L.pstat_chain_extras.argtypes = [vp, i64, dp, dp]
     L.pstat_reduce_device.argtypes = [vp, i32, vp]
     L.pstat_reduce_host.argtypes = [vp, i32, dp]

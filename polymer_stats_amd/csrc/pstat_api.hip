@@ -332,7 +332,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_HIP(hipMemsetAsync(h->d_queue, 0, sizeof(int) * sweep_queue_ints(h->args), h->stream));
   CREATE_HIP(hipMemcpyAsync(h->d_cases, h->cases.data(), sizeof(CaseConst) * (size_t)ncases,
                             hipMemcpyHostToDevice, h->stream));
-  const InitOpts io{h->base.use_x0, h->base.x0_phi, h->base.x0_theta, h->base.dx0_phi, h->base.dx0_theta};
+  const InitOpts io{h->base.use_x0, h->base.x0_phi, h->base.x0_theta, h->base.dx0_phi, h->base.dx0_theta, nullptr};
   CREATE_HIP(launch_init(h->cfg, h->args, h->S, h->d_cases, h->base.phi_step, h->base.theta_step, io, h->stream));
   if (inter) {  // a zero-step launch derives r, p, U (with the pair energy) from the fresh angles
     h->args.nsteps = 0; h->args.step0 = 0;
@@ -499,6 +499,41 @@ int pstat_set_kT(pstat_handle *h, int32_t icase, double kT) {
   for (int i = 0; i < h->ncases; ++i)
     if (icase < 0 || icase == i) h->cases[(size_t)i].kT = kT;
   HIP_TRY(hipMemcpy(h->d_cases, h->cases.data(), sizeof(CaseConst) * (size_t)h->ncases, hipMemcpyHostToDevice));
+  return PSTAT_OK;
+}
+
+int pstat_restart_from_x0(pstat_handle *h, const double *x0, int64_t len, double dx0_phi, double dx0_theta) {
+  if (!h || !x0) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  if (len != 2 && len != 2 * h->base.n)
+    return fail(PSTAT_ERR_INVALID_ARG, "Invalid input for 'x0': length %lld is neither 2 nor 2 * num-monomers",
+                (long long)len);                                                      // inc/eap_chain.jl:77
+  for (int64_t i = 0; i < len; ++i)
+    if (!std::isfinite(x0[i])) return fail(PSTAT_ERR_INVALID_ARG, "non-finite x0[%lld]", (long long)i);
+  if (!std::isfinite(dx0_phi) || !std::isfinite(dx0_theta)) return fail(PSTAT_ERR_INVALID_ARG, "non-finite dx0");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double *d_x0 = nullptr;
+  InitOpts io{1, x0[0], x0[1], dx0_phi, dx0_theta, nullptr};
+  if (len != 2) {
+    HIP_TRY(hipMalloc((void **)&d_x0, sizeof(double) * (size_t)len));
+    hipError_t e = hipMemcpy(d_x0, x0, sizeof(double) * (size_t)len, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d_x0); return fail(PSTAT_ERR_HIP, "copy of x0 failed: %s", hipGetErrorString(e)); }
+    io.use_x0 = 2;
+    io.x0_vec = d_x0;
+  }
+  hipError_t e = launch_init(h->cfg, h->args, h->S, h->d_cases, h->base.phi_step, h->base.theta_step, io, h->stream);
+  if (e == hipSuccess && all_pairs(h->base.energy_type)) {
+    h->args.nsteps = 0; h->args.step0 = 0;
+    e = h->cfg.move_set == PSTAT_MOVES_CLUSTER ? launch_cluster_wave(h->cfg, h->args, h->S, h->d_cases, h->stream)
+                                               : launch_interacting(h->cfg, h->args, h->S, h->d_cases, 0, h->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (d_x0) (void)hipFree(d_x0);
+  if (e != hipSuccess) return fail(PSTAT_ERR_HIP, "re-initialisation from x0 failed: %s", hipGetErrorString(e));
+  h->steps_recorded = 0;
+  h->step_in_init = 0;
+  h->cfg.lag = 0;
   return PSTAT_OK;
 }
 

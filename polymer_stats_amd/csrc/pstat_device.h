@@ -47,9 +47,10 @@ struct CaseConst {      // physics scalars of one case (inc/eap_chain.jl:89-108)
   double cutoff_radius;   // --cutoff-radius in monomer lengths (energy-type cutoff)
 };
 
-struct InitOpts {       // how EAPChain(pargs) draws the first configuration (inc/eap_chain.jl:61-72)
-  int use_x0;
+struct InitOpts {       // how EAPChain(pargs) draws the first configuration (inc/eap_chain.jl:61-79)
+  int use_x0;           // 0: uniform angles; 1: (x0_phi, x0_theta) for every monomer; 2: per monomer from x0_vec
   double x0_phi, x0_theta, dx0_phi, dx0_theta;
+  const double *x0_vec; // device, [phi1, theta1, phi2, theta2, ...] (use_x0 == 2)
 };
 
 struct SweepArgs {

@@ -50,7 +50,12 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
   R *th = (R *)S.ang, *ph = (R *)S.ang + A.n * S.C;
   G g;
   g.seed(cc.seed, cc.chain_id0 + (uint64_t)local);
-  if (io.use_x0) {  // x0 = [phi; theta] plus Uniform(0, dx0), inc/eap_chain.jl:69-72
+  if (io.use_x0 == 2) {  // per-monomer x0 (interleaved) plus Uniform(0, dx0), inc/eap_chain.jl:73-75
+    for (int64_t i = 0; i < A.n; ++i)
+      ph[i * S.C + c] = store_phi_rad<R>(io.x0_vec[2 * i] + io.dx0_phi * u01<double>(g.next()));
+    for (int64_t i = 0; i < A.n; ++i)
+      th[i * S.C + c] = store_theta_rad<R>(io.x0_vec[2 * i + 1] + io.dx0_theta * u01<double>(g.next()));
+  } else if (io.use_x0) {  // x0 = [phi; theta] plus Uniform(0, dx0), inc/eap_chain.jl:69-72
     for (int64_t i = 0; i < A.n; ++i)
       ph[i * S.C + c] = store_phi_rad<R>(io.x0_phi + io.dx0_phi * u01<double>(g.next()));
     for (int64_t i = 0; i < A.n; ++i)

@@ -66,6 +66,12 @@ class Ensemble:
     def set_kT(self, kT: float, icase: int = -1):
         check(self._L.pstat_set_kT(self._h, icase, float(kT)))
 
+    def restart_from_x0(self, x0, dx0_phi: float, dx0_theta: float):
+        """Start every chain over from x0 ([phi, theta] or interleaved per-monomer angles) + Uniform(0, dx0)."""
+        a = np.ascontiguousarray(x0, dtype=np.float64)
+        check(self._L.pstat_restart_from_x0(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), len(a),
+                                            float(dx0_phi), float(dx0_theta)))
+
     def scale_kT(self, mult: float):
         """kT of every case <- its creation-time kT * mult (one rung of the burn-in ladder for a grid)."""
         check(self._L.pstat_scale_kT(self._h, float(mult)))

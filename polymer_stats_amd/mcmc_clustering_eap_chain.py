@@ -10,8 +10,8 @@ note they differ from mcmc_eap_chain.jl: energy-type defaults to Ising, step-adj
 num-steps to 1e6, and there is a 5-rung burn-in ladder by default).  Added: --num-chains, --seed,
 --devices, --precision, --rng.
 
-All four energy types run on the device (interacting and cutoff: one chain per wavefront, n <= 256).
-Not on the device (the call fails with the reason): an --x0 of length 2 n (per-monomer start angles).
+All four energy types run on the device (interacting and cutoff: one chain per wavefront, n <= 256),
+and both forms of --x0 ([phi; theta] for every monomer, or 2 n interleaved per-monomer angles).
 """
 from __future__ import annotations
 
@@ -140,9 +140,8 @@ def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int)
             raise ReferenceError_(f"Invalid input for 'x0' and/or 'dx0', {pargs['x0']}; {pargs['dx0']}")
         if len(x0) == 2 and len(dx0) >= 2:
             x0kw = dict(use_x0=1, x0_phi=x0[0], x0_theta=x0[1], dx0_phi=dx0[0], dx0_theta=dx0[1])
-        elif len(x0) == 2 * pargs["num-monomers"]:
-            raise _lib.PstatError(-4, "option not supported on the device path",
-                                  "a per-monomer --x0 (length 2 n) has no device implementation")
+        elif len(x0) == 2 * pargs["num-monomers"] and len(dx0) >= 2:
+            pass        # per-monomer start: applied after creation (run(): Ensemble.restart_from_x0)
         else:
             raise ReferenceError_(f"Invalid input for 'x0' and/or 'dx0', {pargs['x0']}; {pargs['dx0']}")
     return _lib.default_params(
@@ -230,6 +229,12 @@ def run(pargs: dict):
     except (ValueError, SyntaxError):
         raise ReferenceError_(f"burn-schedule '{pargs['burn-schedule']}' not understood")
     pool = _Pool(pargs, factory=params_from_pargs)
+    if pargs.get("x0") is not None:
+        x0 = julia_vector(pargs["x0"])
+        if len(x0) == 2 * pargs["num-monomers"] and len(x0) != 2:      # inc/eap_chain.jl:73-75
+            dx0 = julia_vector(pargs["dx0"])
+            for e in pool.parts:
+                e.restart_from_x0(x0, dx0[0], dx0[1])
     try:
         for mult in ladder:                                             # :366-383
             _stage(pool, int(pargs["burn-in"]), pargs, pargs["kT"] * mult, write=False)

@@ -110,6 +110,33 @@ def test_f64_bit_parity_burn_in_ladder_and_x0(ps, oracle):
                 x0_theta=1.2, dx0_phi=2 * np.pi, dx0_theta=0.1)
 
 
+def test_f64_bit_parity_per_monomer_x0(ps, oracle):
+    """--x0 of length 2n: [phi1, theta1, phi2, theta2, ...] + Uniform(0, dx0) (inc/eap_chain.jl:73-75), for the
+    chain-per-lane kernel and the chain-per-wavefront one."""
+    for n, extra in ((11, {}), (9, dict(energy_type=1, K1=0.5))):
+        rng = np.random.default_rng(n)
+        x0 = np.c_[rng.uniform(0, 6, n), rng.uniform(0.3, 2.8, n)].reshape(-1)
+        kw = dict(n=n, E0=1.0, Fz=0.5, seed=28, cluster_prob=0.5, dx0_phi=0.4, dx0_theta=0.05, **extra)
+        op, pp = _pair(ps, 800, 8, ps.F64, **kw)
+        from oracle import binding as ob
+        op = ob.make_params(num_steps=800, x0_vec=x0, **kw)
+        with ps.Ensemble(pp) as e:
+            e.advance(50)                                   # whatever happened before is discarded
+            e.restart_from_x0(x0, 0.4, 0.05)
+            g0 = e.chain_state(3)
+            assert np.all((g0["phi"] >= x0[0::2]) & (g0["phi"] < x0[0::2] + 0.4))
+            assert np.all((g0["theta"] >= x0[1::2]) & (g0["theta"] < x0[1::2] + 0.05))
+            _run_gpu(e, pp, 800)
+            for c in range(8):
+                o = oracle.run(op, chain_id=c, mode="cluster", trace=True)
+                g = e.chain_state(c)
+                assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi)
+                assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total
+                np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-9, atol=1e-9)
+            with pytest.raises(ps.PstatError):
+                e.restart_from_x0(x0[:5], 0.4, 0.05)
+
+
 def test_f64_bit_parity_cluster_umbrella(ps, oracle):
     _bit_parity(ps, oracle, 3000, 64, n=14, E0=1.5, K1=1.0, K2=0.0, Fz=0.2, seed=27, umbrella=1,
                 bend_mod=0.4, bend_angle=0.2, cluster_prob=0.5, steps_per_adjust=500)

@@ -153,9 +153,8 @@ def test_cluster_julia_vector_literals_and_params():
     p = chost.params_from_pargs(chost.default_pargs(**{"energy-type": "cutoff", "cutoff-radius": 3.5}), 1, 0, 0)
     assert (p.energy_type, p.cutoff_radius) == (ps.CUTOFF, 3.5)
     assert chost.params_from_pargs(chost.default_pargs(**{"energy-type": "interacting"}), 1, 0, 0).energy_type == ps.INTERACTING
-    with pytest.raises(ps.PstatError) as ei:
-        chost.params_from_pargs(chost.default_pargs(x0="[" + "; ".join(["0.1"] * 200) + "]"), 1, 0, 0)
-    assert ei.value.code == -4
+    p = chost.params_from_pargs(chost.default_pargs(x0="[" + "; ".join(["0.1"] * 200) + "]"), 1, 0, 0)
+    assert p.use_x0 == 0          # the per-monomer form is applied after creation (restart_from_x0)
     with pytest.raises(host.ReferenceError_):
         chost.main(["--profile"])
 
