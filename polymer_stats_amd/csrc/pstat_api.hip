@@ -104,8 +104,6 @@ int validate(const pstat_params *c, int ncases) {
   if (b.move_set != PSTAT_MOVES_SINGLE && b.move_set != PSTAT_MOVES_CLUSTER)
     return fail(PSTAT_ERR_INVALID_ARG, "move_set must be PSTAT_MOVES_SINGLE or PSTAT_MOVES_CLUSTER");
   if (b.move_set == PSTAT_MOVES_CLUSTER) {
-    if (b.precision == PSTAT_Q16)
-      return fail(PSTAT_ERR_UNSUPPORTED, "cluster moves are not implemented for the lattice state (PSTAT_Q16)");
     if (b.do_flips) return fail(PSTAT_ERR_INVALID_ARG, "mcmc_clustering_eap_chain.jl has no --do-flips");
     if (b.n < 2) return fail(PSTAT_ERR_INVALID_ARG, "cluster moves need num-monomers >= 2 (the mean bond angle)");
   }

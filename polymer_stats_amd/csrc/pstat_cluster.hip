@@ -59,14 +59,33 @@ template <typename R> __device__ __forceinline__ R bond_angle(const V3<R> &a, co
   return acos_r(fmin((R)1, fmax((R)-1, dot3(a, b))));
 }
 
-template <typename R, typename G, int CT, int EN>
+// ST = 0: the LDS cell is the (theta, phi) pair in R.  ST = 1 (PSTAT_Q16, R = float): one 32-bit word,
+// theta lattice index in the low half and phi index in the high half (pstat_math.h); the reflection
+// theta -> pi - theta is k -> 65535 - k, exact on the midpoint lattice.
+template <typename R, typename G, int CT, int EN, int ST>
 __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const DevState &S, const CaseConst &cc,
                                                     const int umb_on, unsigned char *smem, const int lane,
                                                     const int64_t c, int64_t step, int64_t remaining) {
   using R2 = typename Vec2<R>::type;
   using AG = Ang<R>;
   using T3 = V3<R>;
-  R2 *ang = reinterpret_cast<R2 *>(smem);  // [n][lanes], (theta, phi)
+  constexpr bool Q = ST == 1;
+  static_assert(!Q || sizeof(R) == 4, "the lattice state runs on f32 arithmetic");
+  using Cell = typename std::conditional<Q, uint32_t, R2>::type;
+  Cell *ang = reinterpret_cast<Cell *>(smem);  // [n][lanes]
+  auto dec = [](const Cell v) __attribute__((always_inline)) -> R2 {   // cell -> (theta, phi) in the unit of Ang<R>
+    if constexpr (Q) { R2 a; a.x = q16_theta_turns(v & 0xFFFFu); a.y = q16_phi_turns(v >> 16); return a; }
+    else return v;
+  };
+  auto refl_cell = [](const Cell v) __attribute__((always_inline)) -> Cell {   // refl_n! on a stored monomer
+    if constexpr (Q) return (v & 0xFFFF0000u) | (65535u - (v & 0xFFFFu));
+    else {
+      Cell o = v;
+      if constexpr (sizeof(R) == 8) o.x = fmin(AG::theta_max, fmax((R)0, v.x + (AG::theta_max - 2 * v.x)));
+      else o.x = AG::theta_max - v.x;
+      return o;
+    }
+  };
   const int lanes = A.lanes;
   const int64_t C = S.C;
   const int n = (int)A.n;
@@ -81,7 +100,12 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
   const R cprob = (R)cc.cluster_prob;
   (void)hb; (void)nbeta_log2e; (void)kT;
 
-  {  // ---- fill
+  if constexpr (Q) {  // ---- fill
+    const uint16_t *gth = (const uint16_t *)S.ang, *gph = (const uint16_t *)S.ang + (int64_t)n * C;
+#pragma unroll 8
+    for (int i = 0; i < n; ++i)
+      ang[i * lanes + lane] = (uint32_t)gth[(int64_t)i * C + c] | ((uint32_t)gph[(int64_t)i * C + c] << 16);
+  } else {
     const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
 #pragma unroll 8
     for (int i = 0; i < n; ++i) {
@@ -91,10 +115,13 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
       ang[i * lanes + lane] = v;
     }
   }
+  // step sizes in the unit the proposal is added in: radians (f64), turns (f32), lattice cells (q16)
+  constexpr double th_unit = Q ? 3.14159265358979323846 / 65536.0 : AG::unit;
+  constexpr double ph_unit = Q ? 6.28318530717958647692 / 65536.0 : AG::unit;
   G g;
   g.load(S.rng + c, C);
   double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
-  R phistep = (R)(phistep_d / AG::unit), thstep = (R)(thstep_d / AG::unit);
+  R phistep = (R)(phistep_d / ph_unit), thstep = (R)(thstep_d / th_unit);
   int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
   R Orx = (R)S.obs[OBS_R1 * C + c], Ory = (R)S.obs[OBS_R2 * C + c], Orz = (R)S.obs[OBS_R3 * C + c];
@@ -144,7 +171,7 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
     else sm.z += q;
   };
   auto load_nm = [&](const int i, T3 &nh, T3 &mu) __attribute__((always_inline)) -> bool {
-    return nm_of(ang[i * lanes + lane], nh, mu);
+    return nm_of(dec(ang[i * lanes + lane]), nh, mu);
   };
   // reflection through the plane normal to the field: refl_n!, inc/eap_chain.jl:263-265
   auto refl_theta = [&](const R th) __attribute__((always_inline)) -> R {
@@ -178,10 +205,23 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
       const int idx = (int)__umulhi(g.next(), (uint32_t)n);
       const uint32_t wphi = g.next(), wth = g.next();
       const int cell = idx * lanes + lane;
-      const R2 a0 = ang[cell];
+      const Cell c0 = ang[cell];
+      const R2 a0 = dec(c0);
       const R th0 = a0.x, ph0 = a0.y;
-      const R ph1 = AG::wrap(ph0 + phistep * sym11<R>(wphi));
-      const R th1 = fmin(AG::theta_max, fmax((R)0, th0 + thstep * sym11<R>(wth)));
+      R th1, ph1;
+      bool inside = true;       // q16: the trial theta stayed on the lattice (else: the reference's clamp => rejected)
+      uint32_t k1c = 0, j1 = 0;
+      if constexpr (Q) {
+        const int k1 = (int)(c0 & 0xFFFFu) + q16_disp(thstep, sym11<R>(wth));
+        j1 = ((c0 >> 16) + (uint32_t)q16_disp(phistep, sym11<R>(wphi))) & 0xFFFFu;
+        inside = (uint32_t)k1 < 65536u;
+        k1c = (uint32_t)min(max(k1, 0), 65535);
+        th1 = q16_theta_turns(k1c);
+        ph1 = q16_phi_turns(j1);
+      } else {
+        ph1 = AG::wrap(ph0 + phistep * sym11<R>(wphi));
+        th1 = fmin(AG::theta_max, fmax((R)0, th0 + thstep * sym11<R>(wth)));
+      }
       R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
       AG::sc(th0, &st0, &ct0);
       AG::sc(th1, &st1, &ct1);
@@ -238,10 +278,10 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
         bool eBu = edgeR, eBl = edgeL;
         bool gu = hasR, gl = hasL;
         int rowu = min(idx + 2, n - 1), rowl = max(idx - 2, 0);
-        R2 au = ang[rowu * lanes + lane], al = ang[rowl * lanes + lane];
+        Cell au = ang[rowu * lanes + lane], al = ang[rowl * lanes + lane];
         while (gu || gl) {
           T3 Cu, Cl;
-          const bool eCu = nhat_of(au, Cu), eCl = nhat_of(al, Cl);
+          const bool eCu = nhat_of(dec(au), Cu), eCl = nhat_of(dec(al), Cl);
           rowu = min(rowu + 1, n - 1); rowl = max(rowl - 1, 0);
           au = ang[rowu * lanes + lane]; al = ang[rowl * lanes + lane];
           {
@@ -326,26 +366,25 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
         ok = bits12(weps) * st0 < fma_r(st1, e, st0);   // (1 + u) sin0 < sin1 e alpha + sin0
       }
 
-      ok = ok && !edge;
+      ok = ok && !edge && inside;
 
       // ---- commit
       if (ok) {
-        R2 a1;
-        a1.x = flipped ? refl_theta(th1) : th1;
-        a1.y = ph1;
+        Cell a1;
+        if constexpr (Q) a1 = (flipped ? 65535u - k1c : k1c) | (j1 << 16);
+        else { a1.x = flipped ? refl_theta(th1) : th1; a1.y = ph1; }
         ang[cell] = a1;
         if (flipped) {
           // four members per pass: the reads are independent, slots past `upper` alias `upper` and
           // write the same value again; the moved monomer (already stored) is passed through
           for (int i = lower; i <= upper; i += 4) {
-            R2 v[4];
+            Cell v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ang[min(i + j, upper) * lanes + lane];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int m = min(i + j, upper);
-              v[j].x = m == idx ? v[j].x : refl_theta(v[j].x);
-              ang[m * lanes + lane] = v[j];
+              ang[m * lanes + lane] = m == idx ? v[j] : refl_cell(v[j]);
             }
           }
         }
@@ -398,12 +437,19 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
           phistep_d /= A.adj_scale;
           thstep_d /= A.adj_scale;
         }
-        phistep = (R)(phistep_d / AG::unit); thstep = (R)(thstep_d / AG::unit);
+        phistep = (R)(phistep_d / ph_unit); thstep = (R)(thstep_d / th_unit);
       }
     }
   }
 
-  {  // ---- spill
+  if constexpr (Q) {  // ---- spill
+    uint16_t *gth = (uint16_t *)S.ang, *gph = (uint16_t *)S.ang + (int64_t)n * C;
+    for (int i = 0; i < n; ++i) {
+      const uint32_t v = ang[i * lanes + lane];
+      gth[(int64_t)i * C + c] = (uint16_t)(v & 0xFFFFu);
+      gph[(int64_t)i * C + c] = (uint16_t)(v >> 16);
+    }
+  } else {
     R *gth = (R *)S.ang, *gph = (R *)S.ang + (int64_t)n * C;
     for (int i = 0; i < n; ++i) {
       const R2 v = ang[i * lanes + lane];
@@ -426,36 +472,37 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
 }
 
 // the persistent (block, segment) job loop of pstat_device.h around run_cluster_segment
-template <typename R, typename G, int CT, int EN>
+template <typename R, typename G, int CT, int EN, int ST>
 __global__ __launch_bounds__(64) void cluster_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
                                                      int umbrella, int *__restrict__ queue) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
   run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len) {
-    run_cluster_segment<R, G, CT, EN>(A, S, cc, umbrella, smem, lane, chain, first, len);
+    run_cluster_segment<R, G, CT, EN, ST>(A, S, cc, umbrella, smem, lane, chain, first, len);
   }, cases);
 }
 
 using ClusterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int *);
 
-template <typename R, typename G>
+template <typename R, typename G, int ST>
 ClusterFn pick_ct_en(const LaunchCfg &cfg) {
   const bool ising = cfg.energy_type == PSTAT_ISING;
   if (cfg.chain_type == PSTAT_DIELECTRIC)
-    return ising ? cluster_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_ISING>
-                 : cluster_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING>;
-  return ising ? cluster_kernel<R, G, PSTAT_POLAR, PSTAT_ISING>
-               : cluster_kernel<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING>;
+    return ising ? cluster_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_ISING, ST>
+                 : cluster_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING, ST>;
+  return ising ? cluster_kernel<R, G, PSTAT_POLAR, PSTAT_ISING, ST>
+               : cluster_kernel<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING, ST>;
 }
 
 ClusterFn pick_cluster(const LaunchCfg &cfg) {
-  if (cfg.precision == PSTAT_F64)
-    return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_ct_en<double, Xoshiro128pp>(cfg) : pick_ct_en<double, Mwc64x>(cfg);
-  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_ct_en<float, Xoshiro128pp>(cfg) : pick_ct_en<float, Mwc64x>(cfg);
+  const bool xo = cfg.rng == PSTAT_RNG_XOSHIRO128PP;
+  if (cfg.precision == PSTAT_F64) return xo ? pick_ct_en<double, Xoshiro128pp, 0>(cfg) : pick_ct_en<double, Mwc64x, 0>(cfg);
+  if (cfg.precision == PSTAT_Q16) return xo ? pick_ct_en<float, Xoshiro128pp, 1>(cfg) : pick_ct_en<float, Mwc64x, 1>(cfg);
+  return xo ? pick_ct_en<float, Xoshiro128pp, 0>(cfg) : pick_ct_en<float, Mwc64x, 0>(cfg);
 }
 
 int cluster_lds_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
-  return (int)(a.n * a.lanes * (cfg.precision == PSTAT_F64 ? 16 : 8));
+  return (int)(a.n * a.lanes * (cfg.precision == PSTAT_F64 ? 16 : (cfg.precision == PSTAT_Q16 ? 4 : 8)));
 }
 
 }  // namespace
@@ -471,7 +518,8 @@ hipError_t cluster_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *ld
   if (e != hipSuccess) return e;
   if (lds_bytes) *lds_bytes = lds;
   if (blocks_per_cu) *blocks_per_cu = nb;
-  if (name) *name = cfg.precision == PSTAT_F64 ? "cluster_kernel<double>" : "cluster_kernel<float>";
+  if (name) *name = cfg.precision == PSTAT_F64 ? "cluster_kernel<double>"
+                 : (cfg.precision == PSTAT_Q16 ? "cluster_kernel<float, q16 state>" : "cluster_kernel<float>");
   return hipSuccess;
 }
 

@@ -203,6 +203,28 @@ def test_f32_cluster_statistics(ps, oracle, energy_type, K1):
     assert np.all(np.abs(zx) < 4.5), (zx, gx, ex.mean(0))
 
 
+@pytest.mark.parametrize("energy_type,K1", [(0, 1.0), (2, 0.2)])
+def test_q16_cluster_matches_f64_kernel(ps, energy_type, K1):
+    """Opt-in lattice state in the cluster kernel: pooled averages against the f64 cluster kernel (itself
+    bit-exact vs the oracle) under the same protocol, two-sample z < 4.5; the state stays on the lattice."""
+    out = {}
+    for prec in (ps.F64, ps.Q16):
+        pp = ps.default_params(n=20, E0=1.0, K1=K1, K2=0.1 * K1, Fz=0.8, Fx=0.2, kT=1.0, seed=33 + prec, bend_mod=0.5,
+                               bend_angle=0.3, cluster_prob=0.5, energy_type=energy_type, num_chains=4096,
+                               precision=prec, move_set=ps.MOVES_CLUSTER)
+        with ps.Ensemble(pp) as e:
+            _run_gpu(e, pp, 20000, (1.0,), 3000)
+            s = e.summary()
+            out[prec] = (np.r_[s.avg, s.extra_avg, s.acceptance_ratio], np.r_[s.stderr, s.extra_stderr, s.ar_stderr])
+            if prec == ps.Q16:
+                assert b"q16" in e.launch_info().kernel
+                g = e.chain_state(5)
+                k = g["theta"] / np.pi * 65536 - 0.5
+                assert np.allclose(k, np.round(k), atol=1e-6) and k.min() >= 0 and k.max() <= 65535
+    z = (out[ps.Q16][0] - out[ps.F64][0]) / np.sqrt(out[ps.Q16][1] ** 2 + out[ps.F64][1] ** 2 + 1e-300)
+    assert np.all(np.abs(z) < 4.5), z
+
+
 def test_cluster_full_size_properties(ps):
     """Reference-scale ensemble (no oracle): segment invariance, checkpoint round trip, cluster_prob = 1
     leaves the equilibrium of the plain sampler (closed form for E0 = 0, kappa = 0)."""
@@ -235,7 +257,7 @@ def test_cluster_full_size_properties(ps):
 
 
 def test_cluster_errors(ps):
-    for bad in (dict(energy_type=1, n=300), dict(precision=ps.Q16), dict(energy_type=3, precision=ps.Q16)):
+    for bad in (dict(energy_type=1, n=300), dict(energy_type=1, precision=ps.Q16), dict(energy_type=3, precision=ps.Q16)):
         with pytest.raises(ps.PstatError) as ei:
             ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, **{"n": 16, **bad}))
         assert ei.value.code == -4

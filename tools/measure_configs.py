@@ -76,13 +76,13 @@ def main():
         grid = [P(n=200, E0=0.2 * i, kT=10 ** (-2 + 0.2 * j), K1=1.0, num_chains=128, precision=prec, seed=1000 + 21 * i + j,
                   energy_type=ps.ISING) for i in range(26) for j in range(21)]
         res.append(run(ps, torch, f"C5 n=200 (E0,kT) grid 546 points x 128 chains, Ising [{tag}]", grid, 50000 // q))
+        # C6: the clustering main as run/Ising_2025-12-18.jl:25-27 and run/K1_E0-kT-phase.jl:45 launch it
+        # (Ising energy, K2-only dielectric, default cluster-prob 0.5, step-adjust-ub 0.40)
+        for et, en in ((ps.ISING, "Ising"), (ps.NONINTERACTING, "non-interacting")):
+            res.append(run(ps, torch, f"C6 clustering main n=100 {en} E0=1 K1=0 K2=1 kT=1 [{tag}]",
+                           P(n=100, E0=1.0, K1=0.0, K2=1.0, kT=1.0, energy_type=et, num_chains=65536, precision=prec,
+                             seed=6, move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, adj_ub=0.40), 20000 // q))
         if prec != ps.Q16:
-            # C6: the clustering main as run/Ising_2025-12-18.jl:25-27 and run/K1_E0-kT-phase.jl:45 launch it
-            # (Ising energy, K2-only dielectric, default cluster-prob 0.5, step-adjust-ub 0.40)
-            for et, en in ((ps.ISING, "Ising"), (ps.NONINTERACTING, "non-interacting")):
-                res.append(run(ps, torch, f"C6 clustering main n=100 {en} E0=1 K1=0 K2=1 kT=1 [{tag}]",
-                               P(n=100, E0=1.0, K1=0.0, K2=1.0, kT=1.0, energy_type=et, num_chains=65536, precision=prec,
-                                 seed=6, move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, adj_ub=0.40), 20000 // q))
             # C7: clustering main with the all-pairs energies (one chain per wavefront)
             res.append(run(ps, torch, f"C7 clustering main n=100 interacting E0=1 K1=1 Fz=0.5 [{tag}]",
                            P(n=100, E0=1.0, K1=1.0, Fz=0.5, energy_type=ps.INTERACTING, num_chains=16384, precision=prec,
