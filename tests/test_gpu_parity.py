@@ -364,6 +364,64 @@ def test_full_size_config2_properties(ps, golden):
     assert 0.5 < s.acceptance_ratio < 0.7
 
 
+def test_full_size_config4_properties(ps):
+    """BASELINE configs[3] at its full size (interacting dielectric, n = 64, 16 384 chains): launch
+    splitting and checkpoint/restore are bit-invariant; with E0 = 0 a dielectric chain carries no dipoles, the
+    pair energy vanishes and the all-pairs kernel must sit on the freely-jointed-chain closed form
+    <r_z> = n b (coth x - 1/x), x = F b / kT (its O(n^2) machinery still runs)."""
+    nch, n = 16384, 64
+    pp = ps.default_params(num_chains=nch, precision=ps.F32, n=n, E0=1.0, K1=1.0, Fz=0.5, energy_type=ps.INTERACTING, seed=44)
+    with ps.Ensemble(pp) as a, ps.Ensemble(pp) as b:
+        a.advance(600)
+        blob = a.checkpoint()
+        a.advance(400)
+        b.advance(250); b.advance(350)
+        b.restore(blob)
+        b.advance(400)
+        for c in (0, 4097, nch - 1):
+            ga, gb = a.chain_state(c), b.chain_state(c)
+            assert np.array_equal(ga["theta"], gb["theta"]) and np.array_equal(ga["rng"], gb["rng"])
+            assert np.array_equal(ga["sums"], gb["sums"]) and ga["nacc_total"] == gb["nacc_total"]
+        assert a.summary().attempted_updates == float(nch) * 1000
+    pp = ps.default_params(num_chains=nch, precision=ps.F32, n=n, E0=0.0, K1=1.0, Fz=1.0, energy_type=ps.INTERACTING, seed=45)
+    with ps.Ensemble(pp) as e:
+        e.advance(6000)
+        e.reset_averages()
+        e.advance(4000)
+        s = e.summary()
+    want = n * (1 / np.tanh(1.0) - 1.0)
+    assert abs(s.avg[2] - want) < 5 * s.stderr[2] + 2e-3 * want, (s.avg[2], want, s.stderr[2])
+    assert abs(s.avg[14] + want) < 5 * s.stderr[14] + 2e-3 * want          # U = -F r_z when E0 = 0
+    assert s.avg[13] == 0.0                                                   # no dipoles at all
+
+
+def test_full_size_config5_grid_properties(ps):
+    """BASELINE configs[4]: the 546-point (E0, kT) grid at n = 200 in ONE launch.  A grid point inside the
+    batch follows bit-identically the trajectory of the same case run alone (cases never interact); E0 = 0 columns sit on
+    <r_z> = 0 and <r^2> = n b^2 for every temperature; the acceptance ratio stays inside the adaptation band
+    or at its caps."""
+    grid = [(0.2 * i, 10.0 ** (-2 + 0.2 * j)) for i in range(26) for j in range(21)]
+    mk = lambda k: ps.default_params(n=200, E0=grid[k][0], kT=grid[k][1], K1=1.0, num_chains=64, seed=1000 + k,
+                                     precision=ps.F32, energy_type=ps.ISING)
+    with ps.Ensemble([mk(k) for k in range(len(grid))]) as e:
+        e.advance(6000)
+        picks = (0, 20, 273, 545)
+        states = {k: e.chain_state(k * 64 + 63) for k in picks}
+        sums = {k: e.summary(k) for k in (0, 10, 20)}           # E0 = 0, three temperatures
+    for k in picks:
+        with ps.Ensemble(mk(k)) as one:
+            one.advance(6000)
+            g = one.chain_state(63)
+            assert np.array_equal(g["theta"], states[k]["theta"]) and np.array_equal(g["rng"], states[k]["rng"]), k
+            # (the f32 block partials are folded at segment boundaries too, and the batch is cut into
+            # different time segments than a lone case: same trajectory, sums equal to f32 rounding)
+            np.testing.assert_allclose(g["sums"], states[k]["sums"], rtol=2e-6, atol=1e-3)
+    for k, s in sums.items():
+        assert abs(s.avg[2]) < 5 * s.stderr[2] + 1e-9
+        assert abs(s.avg[6] - 200.0) < 5 * s.stderr[6] + 2.0, (k, s.avg[6], s.stderr[6])
+        assert 0.1 < s.acceptance_ratio <= 1.0
+
+
 def test_edge_shapes(ps, oracle):
     """Ragged and degenerate shapes: one chain, chain counts that do not fill a wave, n = 1 and 2,
     one-step launches, zero-step launches, a field so strong that almost nothing is accepted."""
