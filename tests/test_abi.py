@@ -106,3 +106,25 @@ def test_product_never_touches_the_oracle():
                 assert "eap_oracle" not in code, (f, code)
     out = subprocess.check_output(["ldd", os.path.join(pkg, "libpstat.so")]).decode()
     assert "oracle" not in out
+
+
+def test_julia_hosts_mirror_the_structs(ps):
+    """The (unexecuted) Julia hosts declare PstatParams / PstatSummary by hand: same field names, order and
+    widths as the ctypes mirror that test_struct_layout_matches_header pins against the C header."""
+    import re
+    jl_type = {C.c_double: "Cdouble", C.c_int64: "Int64", C.c_uint64: "UInt64", C.c_int32: "Int32"}
+    for name in ("mcmc_eap_chain.jl", "mcmc_clustering_eap_chain.jl"):
+        src = open(os.path.join(ROOT, "julia", name)).read()
+        body = re.search(r"struct PstatParams\n(.*?)\nend", src, re.S).group(1)
+        got = re.findall(r"(\w+)::(\w+)", body)
+        want = [(f, jl_type[t]) for f, t in ps._lib.Params._fields_]
+        assert got == want, name
+        body = re.search(r"struct PstatSummary\n(.*?)\nend", src, re.S).group(1)
+        got = re.findall(r"(\w+)::([\w{},]+)", body)
+        want = []
+        for f, t in ps._lib.Summary._fields_:
+            want.append((f, jl_type[t] if t in jl_type else "NTuple{%d,Cdouble}" % (C.sizeof(t) // 8)))
+        assert got == want, name
+        # every ccall names a symbol the library exports
+        for sym in set(re.findall(r"ccall\(\(:(\w+), LIBPSTAT\)", src)):
+            assert sym in ps._lib.SYMBOLS, (name, sym)
