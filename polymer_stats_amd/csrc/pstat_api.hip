@@ -401,7 +401,7 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
   }
   const int64_t blocks = h->args.blocks_per_case * h->ncases;
   const char *env = getenv("PSTAT_SEGMENTS");
-  if (const char *ms = getenv("PSTAT_MAX_SPINS")) h->args.max_spins = atoi(ms) > 0 ? atoi(ms) : h->args.max_spins;
+  const char *ms = getenv("PSTAT_MAX_SPINS");
   while (nsteps > 0) {
     const int64_t len = nsteps < max_launch ? nsteps : max_launch;
     int nseg = env ? atoi(env) : choose_segments(blocks, h->slots, len);
@@ -412,6 +412,14 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
     h->args.step0 = h->step_in_init;
     h->args.nseg = nseg;
     h->args.seg_len = (len + nseg - 1) / nseg;
+    // A job waits at most for one segment of its predecessor.  Bound the wait by a generous multiple of the
+    // longest plausible segment (a spin sleeps ~2 us; a step of the cluster kernel on a long, aligned chain
+    // can take tens of us), so that a long launch is never mistaken for a lost predecessor.
+    {
+      const int64_t want = (1ll << 22) + h->args.seg_len * 256;
+      h->args.max_spins = (int32_t)(want < 0x7fffffffLL ? want : 0x7fffffffLL);
+      if (ms && atoi(ms) > 0) h->args.max_spins = atoi(ms);
+    }
     const int64_t jobs = blocks * nseg;
     const unsigned grid = (unsigned)(jobs < h->slots ? jobs : h->slots);
     if (h->cfg.move_set == PSTAT_MOVES_CLUSTER)
