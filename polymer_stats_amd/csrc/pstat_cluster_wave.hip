@@ -107,47 +107,9 @@ __global__ __launch_bounds__(64) void cluster_wave_kernel(SweepArgs A, DevState 
     q.c2sum = wave_allsum<R>(tc2);
   };
 
-  // sum over all pairs (within the cutoff) of configuration q
+  // sum over all pairs (within the cutoff) of configuration q: pstat_wave.h
   auto pair_sum = [&](const Cfg<R, M> &q) -> R {
-    R4 va[M]; R2 vb[M];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-      const R far = (R)1e6 * (R)(lane * M + j + 1);   // parking position of an unused monomer
-      va[j].x = real[j] ? q.xx[j] : far; va[j].y = real[j] ? q.xy[j] : (R)0; va[j].z = real[j] ? q.xz[j] : (R)0;
-      va[j].w = q.mx[j];
-      vb[j].x = q.my[j]; vb[j].y = q.mz[j];
-      ringA[lane * M + j] = va[j]; ringA[(lane + 64) * M + j] = va[j];
-      ringB[lane * M + j] = vb[j]; ringB[(lane + 64) * M + j] = vb[j];
-    }
-    __builtin_amdgcn_wave_barrier();
-    const R4 *pa = ringA + lane * M;
-    const R2 *pb = ringB + lane * M;
-    auto term = [&](const R4 &a, const R2 &ab, const R4 &o, const R2 &ob) -> R {
-      const R dx = a.x - o.x, dy = a.y - o.y, dz = a.z - o.z;
-      const R r2 = dx * dx + dy * dy + dz * dz;
-      const R t = pair_fast(dx, dy, dz, a.w, ab.x, ab.y, o.w, ob.x, ob.y);
-      return r2 > crad2 ? (R)0 : t;                  // inc/eap_chain.jl:178-180
-    };
-    R e = 0, e32 = 0;
-#pragma unroll
-    for (int j = 0; j < M; ++j)
-#pragma unroll
-      for (int jp = j + 1; jp < M; ++jp) e += term(va[j], vb[j], va[jp], vb[jp]);
-#pragma unroll 4
-    for (int k = 1; k <= 32; ++k) {
-      R t = 0;
-#pragma unroll
-      for (int jp = 0; jp < M; ++jp) {
-        const R4 qa = pa[(64 - k) * M + jp];
-        const R2 qb = pb[(64 - k) * M + jp];
-#pragma unroll
-        for (int j = 0; j < M; ++j) t += term(va[j], vb[j], qa, qb);
-      }
-      if (k < 32) e += t; else e32 = t;
-    }
-    e = (e + (R)0.5 * e32) * (R)0.0795774715459476679;   // 1/(4 pi)
-    return wave_allsum<R>(e);
+    return ring_pair_sum<R, M, true>(ringA, ringB, lane, n, crad2, q.xx, q.xy, q.xz, q.mx, q.my, q.mz);
   };
   // inc/energy.jl:13-16, or UCutoff's functor (pair sum only)
   auto total_U = [&](Cfg<R, M> &q) {

@@ -8,14 +8,14 @@
 // scalar ALU beside the vector work.
 //   * trial positions: a move of monomer idx shifts x_idx by b/2 dn and every x_j, j > idx, by b dn
 //     (x_i = b (sum_{k<=i} n_k - n_i/2), inc/eap_chain.jl:49-51): three FMAs per lane, no scan;
-//   * the n(n-1)/2 pair terms: the trial (x, mu) of every monomer is staged once per step in a
-//     128-entry LDS ring (entry m = monomer m mod 64), so "lane i meets lane i-k" is a read at a
-//     COMPILE-TIME offset from the lane's own slot: one ds_read_b128 + one ds_read_b64 per partner and
-//     no VALU work for addressing or data movement (a DPP rotation costs 6 quarter-rate moves per
-//     partner, measured in tools/ubench).  Rotations k = 1..31 meet every pair at circular distance
-//     k once; rotation 32 meets each of its pairs from both ends and is weighted 1/2: 2016 pairs at
-//     n = 64.  Lanes >= n carry zero dipoles at distinct far-away positions, so they contribute
-//     exactly 0 without a per-pair select;
+//   * the n(n-1)/2 pair terms (ring_pair_sum, pstat_wave.h): the trial (x, mu) of every monomer is staged
+//     once per step in an LDS ring of the L = ceil(n/M) lanes that carry the chain, so "lane i meets
+//     lane i-k" is one ds_read_b128 + one ds_read_b64 per partner monomer at an offset from the lane's own
+//     slot and no VALU work for data movement (a DPP rotation costs 6 quarter-rate moves per partner,
+//     measured in tools/ubench).  Rotations k = 1..L/2-1 meet every pair of lanes once; rotation L/2 meets
+//     its pairs from both ends and is weighted 1/2: 2016 pairs in 32 rotations at n = 64, 4950 pairs in
+//     25 rotations of 4 terms at n = 100.  Unused slots carry zero dipoles at distinct far-away positions,
+//     so they contribute exactly 0 without a per-pair select;
 //   * one butterfly reduction gives the new pair energy to all lanes.
 // Full recomputation per step is the reference's own cost model (it recomputes U from scratch,
 // inc/eap_chain.jl:254); an exact incremental form would still touch ~n^2/6 pairs twice.
@@ -33,8 +33,9 @@
 namespace pstat {
 
 // M consecutive monomers per lane: lane l owns monomers l*M .. l*M + M-1 (n <= 64 M).
+// (f64, M = 1 sits at the 256-VGPR boundary: ask for two waves per SIMD so that it stays on the good side)
 template <typename R, typename G, int CT, int M>
-__global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S,
+__global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void interacting_kernel(SweepArgs A, DevState S,
                                                          const CaseConst *__restrict__ cases,
                                                          int do_flips, int use_lag, int umb,
                                                          int reinit_mode /* 0 | 1 metropolis | 2 forced */) {
@@ -113,48 +114,10 @@ __global__ __launch_bounds__(64) void interacting_kernel(SweepArgs A, DevState S
     usum = wave_allsum<R>(mhalfE0 * tmz);
   };
 
-  // sum over all pairs of a configuration (tx, tm) held M monomers per lane
+  // sum over all pairs of a configuration (tx, tm) held M monomers per lane: pstat_wave.h
   auto pair_sum = [&](const R (&tx)[M], const R (&ty)[M], const R (&tz)[M], const R (&tmx)[M],
                       const R (&tmy)[M], const R (&tmz)[M]) -> R {
-    R4 va[M]; R2 vb[M];
-    __builtin_amdgcn_wave_barrier();            // previous step's reads are done (in-order LDS)
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-      const R far = (R)1e6 * (R)(lane * M + j + 1);   // parking position of an unused monomer
-      va[j].x = real[j] ? tx[j] : far; va[j].y = real[j] ? ty[j] : (R)0; va[j].z = real[j] ? tz[j] : (R)0;
-      va[j].w = tmx[j];
-      vb[j].x = tmy[j]; vb[j].y = tmz[j];
-      ringA[lane * M + j] = va[j]; ringA[(lane + 64) * M + j] = va[j];
-      ringB[lane * M + j] = vb[j]; ringB[(lane + 64) * M + j] = vb[j];
-    }
-    __builtin_amdgcn_wave_barrier();            // one wave: LDS executes its own ops in order
-    const R4 *pa = ringA + lane * M;
-    const R2 *pb = ringB + lane * M;
-    R e = 0, e32 = 0;
-    // pairs inside the lane
-#pragma unroll
-    for (int j = 0; j < M; ++j)
-#pragma unroll
-      for (int jp = j + 1; jp < M; ++jp)
-        e += pair_fast(va[j].x - va[jp].x, va[j].y - va[jp].y, va[j].z - va[jp].z, va[j].w, vb[j].x, vb[j].y,
-                       va[jp].w, vb[jp].x, vb[jp].y);
-    // pairs with the monomers of lane - k, k = 1..32 (k = 32 is met from both ends: weight 1/2)
-#pragma unroll 4
-    for (int k = 1; k <= 32; ++k) {
-      R t = 0;
-#pragma unroll
-      for (int jp = 0; jp < M; ++jp) {
-        const R4 qa = pa[(64 - k) * M + jp];
-        const R2 qb = pb[(64 - k) * M + jp];
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-          t += pair_fast(va[j].x - qa.x, va[j].y - qa.y, va[j].z - qa.z, va[j].w, vb[j].x, vb[j].y,
-                         qa.w, qb.x, qb.y);
-      }
-      if (k < 32) e += t; else e32 = t;
-    }
-    e = (e + (R)0.5 * e32) * (R)0.0795774715459476679;   // 1/(4 pi)
-    return wave_allsum<R>(e);
+    return ring_pair_sum<R, M, false>(ringA, ringB, lane, n, (R)0, tx, ty, tz, tmx, tmy, tmz);
   };
   // value of per-monomer array `a` at monomer idx (wave-uniform result)
   auto at_idx = [&](const R (&a)[M], int owner, int slot) -> R {
