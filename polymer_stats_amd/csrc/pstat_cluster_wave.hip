@@ -109,7 +109,8 @@ __global__ __launch_bounds__(64) void cluster_wave_kernel(SweepArgs A, DevState 
 
   // sum over all pairs (within the cutoff) of configuration q: pstat_wave.h
   auto pair_sum = [&](const Cfg<R, M> &q) -> R {
-    return ring_pair_sum<R, M, true>(ringA, ringB, lane, n, crad2, q.xx, q.xy, q.xz, q.mx, q.my, q.mz);
+    if constexpr (sizeof(R) == 4 && M >= 2) return ring_pair_sum_pk<M, true>(ringA, ringB, lane, n, crad2, q.xx, q.xy, q.xz, q.mx, q.my, q.mz);
+    else return ring_pair_sum<R, M, true>(ringA, ringB, lane, n, crad2, q.xx, q.xy, q.xz, q.mx, q.my, q.mz);
   };
   // inc/energy.jl:13-16, or UCutoff's functor (pair sum only)
   auto total_U = [&](Cfg<R, M> &q) {

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void intera
   // sum over all pairs of a configuration (tx, tm) held M monomers per lane: pstat_wave.h
   auto pair_sum = [&](const R (&tx)[M], const R (&ty)[M], const R (&tz)[M], const R (&tmx)[M],
                       const R (&tmy)[M], const R (&tmz)[M]) -> R {
-    return ring_pair_sum<R, M, false>(ringA, ringB, lane, n, (R)0, tx, ty, tz, tmx, tmy, tmz);
+    if constexpr (sizeof(R) == 4 && M >= 2) return ring_pair_sum_pk<M, false>(ringA, ringB, lane, n, 0.0f, tx, ty, tz, tmx, tmy, tmz);
+    else return ring_pair_sum<R, M, false>(ringA, ringB, lane, n, (R)0, tx, ty, tz, tmx, tmy, tmz);
   };
   // value of per-monomer array `a` at monomer idx (wave-uniform result)
   auto at_idx = [&](const R (&a)[M], int owner, int slot) -> R {

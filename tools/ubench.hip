@@ -11,18 +11,24 @@
 constexpr int ITERS = 4096;
 constexpr int ACC = 8;
 
-enum Op { FMA32, MULLO, MULHI, SIN, EXP2, RCP, FMA64, ADD64, XORSHIFT, CVT, PKFMA, LDSB64, MAD64, ALIGNBIT, XOR32, ADDU32, XOSHIRO, MWC64X, DPP_WAVE_ROR, DPP_ROW_ROR, BPERMUTE, DPP_WAVE_ROR_IND };
+enum Op { PKFMA_IND, PKADD_IND, FMA32, MULLO, MULHI, SIN, EXP2, RCP, FMA64, ADD64, XORSHIFT, CVT, PKFMA, LDSB64, MAD64, ALIGNBIT, XOR32, ADDU32, XOSHIRO, MWC64X, DPP_WAVE_ROR, DPP_ROW_ROR, BPERMUTE, DPP_WAVE_ROR_IND };
 
 template <int OP>
 __global__ __launch_bounds__(64) void rate_kernel(float *out, int nrows) {
   extern __shared__ float2 lds[];
   float a[ACC]; uint32_t u[ACC]; double d[ACC];
+  typedef float v2q __attribute__((ext_vector_type(2)));
+  v2q pk[ACC];
+  for (int i = 0; i < ACC; ++i) pk[i] = (v2q){0.001f * (threadIdx.x + i + 1), 0.002f * (threadIdx.x + i + 1)};
   for (int i = 0; i < ACC; ++i) { a[i] = 0.001f * (threadIdx.x + i + 1); u[i] = threadIdx.x * 2654435761u + i; d[i] = a[i]; }
   if (OP == LDSB64) for (int r = 0; r < nrows; ++r) lds[r * 64 + threadIdx.x] = make_float2(r, threadIdx.x);
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int i = 0; i < ACC; ++i) {
       if (OP == FMA32) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
+      // packed ops on ACC independent register pairs: the issue cost of v_pk_fma_f32 / v_pk_add_f32 themselves
+      if (OP == PKFMA_IND) pk[i] = __builtin_elementwise_fma(pk[i], (v2q){1.0001f, 1.0002f}, (v2q){0.5f, 0.25f});
+      if (OP == PKADD_IND) pk[i] = pk[i] + (v2q){0.5f, 0.25f};
       if (OP == MULLO) u[i] = u[i] * 0xD2511F53u + 1u;
       if (OP == MULHI) u[i] = __umulhi(u[i], 0xCD9E8D57u) + 12345u;
       if (OP == SIN) a[i] = __builtin_amdgcn_sinf(a[i]);
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(64) void rate_kernel(float *out, int nrows) {
       }
     }
   }
-  float s = 0; for (int i = 0; i < ACC; ++i) s += a[i] + (float)u[i] + (float)d[i];
+  float s = 0; for (int i = 0; i < ACC; ++i) s += a[i] + (float)u[i] + (float)d[i] + pk[i].x + pk[i].y;
   if (s == 123.456f) out[0] = s;
 }
 
@@ -149,7 +155,8 @@ int main() {
     run<FMA32>("fma_f32", w); run<MULLO>("mul_lo_u32", w); run<MULHI>("mul_hi_u32", w);
     run<SIN>("v_sin_f32", w); run<EXP2>("v_exp_f32", w); run<RCP>("v_rcp_f32", w);
     run<FMA64>("fma_f64", w); run<ADD64>("add_f64", w); run<XORSHIFT>("xor/shl/rot", w);
-    run<CVT>("cvt+add", w); run<PKFMA>("pk_fma_f32", w);
+    run<CVT>("cvt+add", w); run<PKFMA>("pk_fma_f32 (pair assembled per op)", w);
+    run<PKFMA_IND>("pk_fma_f32 independent", w); run<PKADD_IND>("pk_add_f32 independent", w);
   }
   for (int w : {4, 8}) { run<MAD64>("mad_u64_u32", w); run<ALIGNBIT>("alignbit", w); run<XOR32>("xor_b32", w); run<ADDU32>("add_u32", w); }
   for (int w : {4, 12, 16}) { run<DPP_WAVE_ROR>("dpp wave_ror", w); run<DPP_ROW_ROR>("dpp row_ror", w); run<BPERMUTE>("ds_bpermute", w); run<DPP_WAVE_ROR_IND>("wave_ror+add", w); }
