@@ -51,8 +51,6 @@ __device__ __forceinline__ float acos_r(float x) {
   return x < 0.0f ? 3.14159265358979f - r : r;
 }
 __device__ __forceinline__ double acos_r(double x) { return acos(x); }
-__device__ __forceinline__ float log_r(float x) { return __logf(x); }
-__device__ __forceinline__ double log_r(double x) { return log(x); }
 
 // psi_j, inc/eap_chain.jl:45-47
 template <typename R> __device__ __forceinline__ R bond_angle(const V3<R> &a, const V3<R> &b) {
@@ -358,9 +356,9 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
       bool ok;
       const R dw = umb ? dus * wscale : (R)0;
       if constexpr (sizeof(R) == 8) {
-        const R delta = -dU / kT + log(st1 / st0) + dw + log(alpha) - lag;
+        const R delta = -dU / kT + log_r(st1 / st0) + dw + log_r(alpha) - lag;
         const R eps = u01<R>(weps);
-        ok = (delta >= 0) || (eps < exp(delta));
+        ok = (delta >= 0) || (eps < exp_r(delta));
       } else {
         const R e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lag) + dU * nbeta_log2e) * alpha;
         ok = bits12(weps) * st0 < fma_r(st1, e, st0);   // (1 + u) sin0 < sin1 e alpha + sin0

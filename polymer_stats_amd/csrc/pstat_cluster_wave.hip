@@ -31,8 +31,7 @@ namespace {
 
 __device__ __forceinline__ float cw_acos(float x) { return acosf(x); }
 __device__ __forceinline__ double cw_acos(double x) { return acos(x); }
-__device__ __forceinline__ float cw_log(float x) { return __logf(x); }
-__device__ __forceinline__ double cw_log(double x) { return log(x); }
+template <typename R> __device__ __forceinline__ R cw_log(R x) { return log_r(x); }
 
 template <typename R, int M>
 struct Cfg {  // one configuration of the chain, M monomers per lane, and its chain totals

@@ -241,8 +241,8 @@ __global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void intera
       bool ok;
       const R dw = du * wscale;   // change of the umbrella weight function (0 if off)
       if constexpr (sizeof(R) == 8) {
-        const R dlt = -dU / kT + log(st1 / st0) + dw - lag;
-        ok = (dlt >= 0) || (eps < exp(dlt));
+        const R dlt = -dU / kT + log_r(st1 / st0) + dw - lag;
+        ok = (dlt >= 0) || (eps < exp_r(dlt));
       } else {
         const R e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lag) + dU * nbeta_log2e);
         ok = eps * st0 < st1 * e;

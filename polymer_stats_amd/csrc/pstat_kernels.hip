@@ -345,8 +345,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       R dw = 0;
       if constexpr (RARE) dw = du * wscale;   // change of the umbrella weight function (0 if off)
       if constexpr (sizeof(R) == 8) {
-        const R delta = -dU / kT + log(st1 / st0) + dw - lag;
-        ok = (delta >= 0) || (eps < exp(delta));
+        const R delta = -dU / kT + log_r(st1 / st0) + dw - lag;
+        ok = (delta >= 0) || (eps < exp_r(delta));
       } else {
         // same test with the logarithm folded away: eps * sin(th0) < sin(th1) * exp(-dU/kT + dw - lag)
         R e;
@@ -409,11 +409,14 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     // faster than dependent ones, and consecutive steps overlap (next step's generator, prefetch and
     // old-state trig against the current step's tail)
     int k = 0;
-    for (; k + (PSTAT_UNROLL - 1) < chunk; k += PSTAT_UNROLL) {
+    // (f64: two steps per block -- its step is ~550 instructions, eight of them overflow the 64 KiB
+    // instruction cache)
+    constexpr int UNROLL = sizeof(R) == 8 ? 2 : PSTAT_UNROLL;
+    for (; k + (UNROLL - 1) < chunk; k += UNROLL) {
 #pragma unroll
-      for (int u = 0; u < PSTAT_UNROLL; u += 2) {
+      for (int u = 0; u < UNROLL; u += 2) {
         one_step(dA, aA, dB, aB, true);
-        one_step(dB, aB, dA, aA, u + 2 < PSTAT_UNROLL || left - k > PSTAT_UNROLL);
+        one_step(dB, aB, dA, aA, u + 2 < UNROLL || left - k > UNROLL);
       }
     }
     for (; k + 1 < chunk; k += 2) {

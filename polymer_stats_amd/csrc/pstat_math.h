@@ -21,8 +21,60 @@ template <> struct K<double> {
   static constexpr double half_pi = 1.57079632679489661923;
 };
 
+// exp and log of a double for the acceptance test of the f64 kernels, ~30 instructions each (the library
+// versions cost several times that).  Classic forms: exp by x = k ln2 + r, |r| <= ln2/2, a degree-13
+// polynomial and one v_ldexp; log by x = 2^k (1 + f), sqrt(1/2) < 1 + f < sqrt(2), s = f / (2 + f) and the
+// fdlibm minimax polynomial in s^2 (the reciprocal is v_rcp_f64 + two Newton steps).  Both within 2 ulp
+// (tools/mathcheck); the test they feed compares against a 23-bit uniform.  exp(-inf) = 0, log(0) = -inf,
+// NaN in => NaN out, as the reject-on-NaN logic of the callers needs.
+__device__ __forceinline__ double exp_f64(const double x) {
+  const double k = rint(x * 1.44269504088896338700e+00);
+  const double hi = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+  const double r = __builtin_fma(-k, 1.90821492927058770002e-10, hi);
+  double p = 1.60590438368216145994e-10;                    // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878680989792e-09);      // 1/12!
+  p = __builtin_fma(p, r, 2.50521083854417187751e-08);
+  p = __builtin_fma(p, r, 2.75573192239858906526e-07);
+  p = __builtin_fma(p, r, 2.75573192239858906526e-06);
+  p = __builtin_fma(p, r, 2.48015873015873015873e-05);
+  p = __builtin_fma(p, r, 1.98412698412698412698e-04);
+  p = __builtin_fma(p, r, 1.38888888888888888889e-03);
+  p = __builtin_fma(p, r, 8.33333333333333333333e-03);
+  p = __builtin_fma(p, r, 4.16666666666666666667e-02);
+  p = __builtin_fma(p, r, 1.66666666666666666667e-01);
+  p = __builtin_fma(p, r, 5.00000000000000000000e-01);
+  const double y = 1.0 + __builtin_fma(p, r * r, r);
+  double v = ldexp(y, (int)k);
+  v = x < -745.2 ? 0.0 : v;           // underflow (also x = -inf, where k and r are not finite)
+  v = x > 709.8 ? __builtin_inf() : v;
+  return v;                           // NaN: both comparisons false, the arithmetic already gave NaN
+}
+__device__ __forceinline__ double log_f64(const double x) {
+  int e = __builtin_amdgcn_frexp_exp(x);
+  double m = __builtin_amdgcn_frexp_mant(x);                // x = m 2^e, 1/2 <= m < 1
+  const bool small = m < 7.07106781186547524401e-01;
+  m = small ? m + m : m;
+  e = small ? e - 1 : e;
+  const double f = m - 1.0, t = 2.0 + f;
+  double rc = __builtin_amdgcn_rcp(t);
+  rc = __builtin_fma(__builtin_fma(-t, rc, 1.0), rc, rc);
+  rc = __builtin_fma(__builtin_fma(-t, rc, 1.0), rc, rc);
+  const double s = f * rc, z = s * s, w = z * z;
+  const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                                       2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t1 + t2, hfsq = 0.5 * f * f, dk = (double)e;
+  double v = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+  v = x == 0.0 ? -__builtin_inf() : v;
+  v = x < 0.0 ? __builtin_nan("") : v;
+  v = x == __builtin_inf() ? x : v;
+  return v;                           // NaN in: frexp propagates it
+}
+
 __device__ __forceinline__ float exp_r(float x) { return __expf(x); }
-__device__ __forceinline__ double exp_r(double x) { return exp(x); }
+__device__ __forceinline__ double exp_r(double x) { return exp_f64(x); }
+__device__ __forceinline__ float log_r(float x) { return __logf(x); }
+__device__ __forceinline__ double log_r(double x) { return log_f64(x); }
 __device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_r(double a, double b, double c) { return a * b + c; }
 
@@ -150,11 +202,48 @@ __device__ __forceinline__ v2d pfma(v2d a, v2d b, v2d c) { return a * b + c; }  
 //   f32: TURNS (theta/2pi in [0, 1/2], phi/2pi in [0, 1)).  gfx950's v_sin_f32/v_cos_f32 take turns
 //        and are accurate to 1.3e-7 absolute there (tools/ubench), phi wraps with one v_fract, and
 //        no range reduction or 1/2pi pre-scale is ever needed.
+// sin and cos of a double, both to < 1 ulp, in ~60 instructions (the library sincos spends ~280 on its
+// double-double range reduction, and the f64 step needs four of them).  Reduction r = x - k pi/2 by
+// three-part Cody-Waite with fused multiply-adds (pi/2 = HI + MID + LO, the k HI product is exact inside
+// the fma; good far beyond any angle a chain reaches -- phi random-walks unwrapped, |phi| stays in the
+// hundreds), then the classic minimax kernels on [-pi/4, pi/4] with the low part of r carried through
+// (the fdlibm polynomials).  |x| >= 1e5 is first folded by whole turns (less accurate there; no chain
+// gets near it).  sin(fl(pi)) = 1.2246e-16 and
+// cos(fl(pi/2)) = 6.1e-17 come out as in glibc, which the clamp corner cases of the parity tests see.
+__device__ __forceinline__ void sincos_f64(double x, double *s, double *c) {
+  if (!(fabs(x) < 1.0e5)) {   // fold by whole turns: 2 pi = HI2 + LO2
+    const double t = rint(x * 1.59154943091895345609e-01);
+    x = __builtin_fma(-t, 2.44929359829470641435e-16, __builtin_fma(-t, 6.28318530717958623200e+00, x));
+  }
+  const double k = rint(x * 6.36619772367581382433e-01);                  // x * 2/pi
+  const double r0 = __builtin_fma(-k, 1.57079632679489655800e+00, x);     // HI
+  const double r = __builtin_fma(-k, 6.12323399573676603587e-17, r0);     // MID
+  double y = __builtin_fma(-k, 6.12323399573676603587e-17, r0 - r);       // what the rounding of r dropped
+  y = __builtin_fma(k, 1.49738490485916983e-33, y);                       // LO = -1.4974e-33
+  const double z = r * r;
+  // sin kernel
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double v = z * r;
+  const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
+  const double ks = r - ((z * (0.5 * y - v * ps) - y) - v * S1);
+  // cos kernel
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double pc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double kc = w + (((1.0 - w) - hz) + (z * pc - r * y));
+  const int q = (int)k & 3;
+  const double sa = (q & 1) ? kc : ks, ca = (q & 1) ? ks : kc;
+  *s = (q & 2) ? -sa : sa;
+  *c = ((q + 1) & 2) ? -ca : ca;
+}
+
 template <typename R> struct Ang;
 template <> struct Ang<double> {
   static constexpr double theta_max = 3.14159265358979323846;
   static constexpr double unit = 1.0;  // radians per stored unit
-  static __device__ __forceinline__ void sc(double x, double *s, double *c) { sincos(x, s, c); }
+  static __device__ __forceinline__ void sc(double x, double *s, double *c) { sincos_f64(x, s, c); }
   static __device__ __forceinline__ double wrap(double x) { return x; }  // phi random-walks, eap_chain.jl:232
 };
 template <> struct Ang<float> {

@@ -1,0 +1,64 @@
+// Accuracy of the f64 device math of polymer_stats_amd/csrc/pstat_math.h (sincos_f64, exp_f64, log_f64) against
+// the host's long-double functions:
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o tools/mathcheck tools/mathcheck.hip && ./tools/mathcheck
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#include "../polymer_stats_amd/csrc/pstat_math.h"
+
+__global__ void run(const double *x, double *s, double *c, double *ex, double *lg, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pstat::sincos_f64(x[i], &s[i], &c[i]);
+  ex[i] = pstat::exp_f64(-fabs(x[i]) * 0.007);     // the acceptance test only ever needs exp of negatives
+  lg[i] = pstat::log_f64(fabs(x[i]));
+}
+
+static double ulps(double got, long double want) {
+  if (want == 0.0L) return got == 0.0 ? 0.0 : 1e9;
+  int e;
+  frexpl(want, &e);
+  return (double)(fabsl((long double)got - want) / ldexpl(1.0L, e - 53));
+}
+
+int main() {
+  const int n = 1 << 22;
+  std::vector<double> x(n);
+  std::mt19937_64 g(7);
+  // (beyond 1e5 the fold-by-turns path of sincos_f64 is only ~1e-11 accurate: not part of the 1-ulp claim)
+  std::uniform_real_distribution<double> th(0.0, M_PI), ph(-2000.0, 2000.0), big(-9.9e4, 9.9e4);
+  for (int i = 0; i < n; ++i) x[i] = i % 4 == 0 ? th(g) : (i % 4 == 1 ? ph(g) : (i % 4 == 2 ? big(g) : std::ldexp(th(g), -(i % 60))));
+  const double special[] = {0.0, M_PI, M_PI / 2, M_PI / 4, 3 * M_PI / 4, -M_PI, 2 * M_PI, 1e-300, 9e4, -7e4, std::nextafter(M_PI, 0.0), 1.0};
+  const int nsp = (int)(sizeof special / sizeof *special);
+  for (int i = 0; i < nsp; ++i) x[i] = special[i];
+  double *d[5];
+  for (auto &p : d) if (hipMalloc(&p, n * 8) != hipSuccess) return 2;
+  if (hipMemcpy(d[0], x.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) return 2;
+  hipLaunchKernelGGL(run, dim3(n / 256), dim3(256), 0, 0, d[0], d[1], d[2], d[3], d[4], n);
+  std::vector<double> s(n), c(n), ex(n), lg(n);
+  if (hipMemcpy(s.data(), d[1], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+  if (hipMemcpy(c.data(), d[2], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+  if (hipMemcpy(ex.data(), d[3], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+  if (hipMemcpy(lg.data(), d[4], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+  double ms = 0, mc = 0, me = 0, ml = 0;
+  int bad = 0;
+  for (int i = 0; i < n; ++i) {
+    const double es = ulps(s[i], sinl((long double)x[i])), ec = ulps(c[i], cosl((long double)x[i]));
+    ms = fmax(ms, es); mc = fmax(mc, ec);
+    if (es > 1.0 || ec > 1.0) ++bad;
+    const double a = fabs(x[i]);
+    const double arg = -a * 0.007;                  // the same double the device saw
+    const double ee = ulps(ex[i], expl((long double)arg));
+    me = fmax(me, ee);
+    if (a > 0) { const double el = ulps(lg[i], logl((long double)a)); ml = fmax(ml, el); if (el > 2.0) ++bad; }
+    if (ee > 2.0) ++bad;
+  }
+  printf("over %d arguments: max error sin %.3f ulp, cos %.3f ulp, exp %.3f ulp, log %.3f ulp; %d out of bounds\n", n, ms, mc, me, ml, bad);
+  printf("sin(fl(pi)) = %.17g (glibc %.17g)  cos(fl(pi/2)) = %.17g (glibc %.17g)  sin(0) = %g  log(0) = %g  log(1) = %g\n", s[1],
+         std::sin(M_PI), c[2], std::cos(M_PI / 2), s[0], lg[0], lg[nsp - 1]);
+  return bad ? 1 : 0;
+}
