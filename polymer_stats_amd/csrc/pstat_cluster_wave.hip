@@ -2,8 +2,8 @@
 // every pair: --energy-type interacting (U_interaction, inc/eap_chain.jl:196-211) and cutoff (UCutoff,
 // :165-192).
 //
-// Mapping is the interacting kernel's (pstat_interacting.hip): ONE CHAIN PER WAVEFRONT, lane l owns M
-// consecutive monomers, chain-level quantities are wave-uniform, the n(n-1)/2 pair terms of a
+// Mapping is the interacting kernel's (pstat_interacting.hip): ONE CHAIN PER WAVEFRONT, lane l owns M = 1, 2,
+// 4 or (f32 only) 8 consecutive monomers, chain-level quantities are wave-uniform, the n(n-1)/2 pair terms of a
 // configuration are met through a 128-entry LDS ring at compile-time offsets.  One chain per wave also
 // makes the cluster move cheap to express: growth is a wave-uniform loop (no lane divergence at all),
 // members are a contiguous index range, and the proposal is evaluated the way the reference does it --
@@ -343,7 +343,11 @@ template <typename G>
 WaveFn pick_g(const LaunchCfg &cfg, int64_t n) {
   if (n <= 64) return pick_gm<G, 1>(cfg);
   if (n <= 128) return pick_gm<G, 2>(cfg);
-  return pick_gm<G, 4>(cfg);
+  if (n <= 256) return pick_gm<G, 4>(cfg);
+  // 8 monomers per lane (n <= 512; the reference's only cutoff-energy sweep, run/phases-big_2023-05-18.jl, uses
+  // n = 400): f32 only -- in f64 two configurations of 8 monomers per lane do not fit the register file
+  const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
+  return diel ? cluster_wave_kernel<float, G, PSTAT_DIELECTRIC, 8> : cluster_wave_kernel<float, G, PSTAT_POLAR, 8>;
 }
 WaveFn pick_wave(const LaunchCfg &cfg, int64_t n) {
   return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_g<Xoshiro128pp>(cfg, n) : pick_g<Mwc64x>(cfg, n);

@@ -227,7 +227,8 @@ __device__ __forceinline__ float ring_pair_sum_pk(float4 *ringA, float2 *ringB, 
     e += M;
   }
   const int cnt = (half - 1) * M;                  // full-weight entries
-#pragma unroll 4
+  constexpr int UNR = M >= 8 ? 1 : (M >= 4 ? 2 : 4);
+#pragma unroll UNR
   for (int q = 0; q < (cnt >> 1); ++q) acc += two_entries(e + 2 * q);
   if constexpr (M == 1) {
     if (cnt & 1) es += one_entry(e + cnt - 1);

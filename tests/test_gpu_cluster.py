@@ -161,6 +161,29 @@ def test_f64_all_pairs_burn_in_ladder(ps, oracle):
                 seed=52, energy_type=1, cluster_prob=0.4, steps_per_adjust=150)
 
 
+def test_f32_cutoff_long_chain_statistics(ps, oracle):
+    """n = 300: 8 monomers per lane (f32 only), the regime of the reference's only cutoff-energy sweep
+    (run/phases-big_2023-05-18.jl: n = 400, --energy-type cutoff).  Short run against the literal oracle."""
+    kw = dict(n=300, E0=1.0, K1=0.3, K2=0.03, Fz=0.3, kT=1.0, seed=54, cluster_prob=0.5, energy_type=3, cutoff_radius=7.5)
+    nsteps = 600
+    op, pp = _pair(ps, nsteps, 512, ps.F32, **kw)
+    with ps.Ensemble(pp) as e:
+        _run_gpu(e, pp, nsteps)
+        s = e.summary()
+        assert e.launch_info().blocks == 512
+    gm, gs = np.array(s.avg), np.array(s.stderr)
+    sums, norm, nacc = oracle.run_many(op, 1 << 20, 96, nthreads=8, mode="cluster")
+    om, os_ = pooled(sums, norm)
+    keep = [i for i, k in enumerate(oracle.OBS_NAMES) if k not in ("Usq", "U")]     # U: heavy 1/r^3 tails
+    z = ((gm - om) / np.sqrt(gs ** 2 + os_ ** 2 + 1e-300))[keep]
+    assert np.all(np.abs(z) < 4.5), (z, gm, om)
+    oar = nacc / nsteps
+    assert abs(s.acceptance_ratio - oar.mean()) < 4.5 * np.hypot(s.ar_stderr, oar.std(ddof=1) / np.sqrt(len(oar))) + 1e-3
+    with pytest.raises(ps.PstatError) as ei:       # f64 stops at 4 monomers per lane
+        ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, n=300, energy_type=3, precision=ps.F64))
+    assert ei.value.code == -4
+
+
 def test_f32_all_pairs_cluster_statistics(ps, oracle):
     kw = dict(n=16, E0=1.0, K1=0.5, K2=0.05, Fz=0.6, kT=1.0, seed=53, bend_mod=0.3, cluster_prob=0.5, energy_type=1)
     nsteps, burn = 3000, 1000
@@ -257,7 +280,8 @@ def test_cluster_full_size_properties(ps):
 
 
 def test_cluster_errors(ps):
-    for bad in (dict(energy_type=1, n=300), dict(energy_type=1, precision=ps.Q16), dict(energy_type=3, precision=ps.Q16)):
+    for bad in (dict(energy_type=1, n=600), dict(energy_type=1, n=300, precision=ps.F64), dict(energy_type=1, precision=ps.Q16),
+                dict(energy_type=3, precision=ps.Q16)):
         with pytest.raises(ps.PstatError) as ei:
             ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, **{"n": 16, **bad}))
         assert ei.value.code == -4
