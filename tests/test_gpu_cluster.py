@@ -305,3 +305,43 @@ def test_scale_kT_is_a_ladder_rung_for_every_case(ps):
         a.scale_kT(1.0)
         with pytest.raises(ps.PstatError):
             a.scale_kT(0.0)
+
+
+def test_f64_bit_parity_random_cluster_configurations(ps, oracle):
+    """Seeded fuzz over the clustering main's options (all four energies, bending, cluster_prob, ladder,
+    both forms of --x0, umbrella, generator): the device trajectory equals the oracle's bit for bit."""
+    rng = np.random.default_rng(20260502)
+    for trial in range(60):
+        et = int(rng.choice([0, 0, 2, 1, 3]))
+        n = int(rng.integers(2, 30)) if et in (0, 2) else int(rng.integers(2, 80))
+        weak = 0.25 if et != 0 else 1.0          # all 1/r^3 energies: stay away from the collapse (see the Ising test)
+        kw = dict(n=n, E0=float(rng.uniform(0, 1.5)), K1=float(rng.uniform(0, 1.0)) * weak, K2=float(rng.uniform(0, 0.4)) * weak,
+                  mu=float(rng.uniform(0.01, 0.5)) * weak, kT=float(10 ** rng.uniform(-0.3, 0.6)), Fz=float(rng.uniform(-1, 1.5)),
+                  Fx=float(rng.choice([0.0, rng.uniform(-1, 1)])), b=float(rng.uniform(0.6, 1.8)),
+                  chain_type=int(rng.integers(0, 2)), energy_type=et, umbrella=int(rng.integers(0, 2)),
+                  bend_mod=float(rng.choice([0.0, rng.uniform(0, 1.5)])), bend_angle=float(rng.uniform(0, 1.0)),
+                  cluster_prob=float(rng.choice([0.0, 0.3, 0.5, 0.8, 1.0])), steps_per_adjust=int(rng.choice([60, 200, 2500])),
+                  rng=int(rng.integers(0, 2)), seed=int(rng.integers(0, 2 ** 40)), cutoff_radius=float(rng.uniform(1.5, 9.0)))
+        nsteps = 300 if et in (1, 3) else 900
+        sched = tuple(float(x) for x in rng.choice([100.0, 10.0, 2.0, 1.0], size=int(rng.integers(0, 3))))
+        burn = int(rng.integers(50, 300))
+        x0mode = int(rng.integers(0, 3))
+        x0 = None
+        if x0mode == 1:
+            kw.update(use_x0=1, x0_phi=float(rng.uniform(0, 6)), x0_theta=float(rng.uniform(0.3, 2.5)), dx0_phi=0.7, dx0_theta=0.1)
+        op, pp = _pair(ps, nsteps, 3, ps.F64, sched, burn, **kw)
+        if x0mode == 2:
+            x0 = np.c_[rng.uniform(0, 6, n), rng.uniform(0.3, 2.5, n)].reshape(-1)
+            from oracle import binding as ob
+            op = ob.make_params(num_steps=nsteps, x0_vec=x0, dx0_phi=0.7, dx0_theta=0.1, burn_in=burn,
+                                burn_sched=list(sched), **kw)
+        with ps.Ensemble(pp) as e:
+            if x0 is not None:
+                e.restart_from_x0(x0, 0.7, 0.1)
+            _run_gpu(e, pp, nsteps, sched, burn)
+            for c in range(3):
+                o = oracle.run(op, chain_id=c, mode="cluster", trace=True)
+                g = e.chain_state(c)
+                assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (trial, kw, sched, x0mode)
+                assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total, (trial, kw)
+                np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-8, atol=1e-8, err_msg=str((trial, kw)))

@@ -464,3 +464,39 @@ def test_equilibrium_after_burn_in_matches_closed_form_sharply(ps, golden, prec)
     z = np.array([(avg[k] - eq[name]) / (se[k] + 1e-300) for k, name in enumerate(ps.OBS_NAMES)])
     assert np.all(np.abs(z) < 5.0), dict(zip(ps.OBS_NAMES, np.round(z, 2)))
     assert se[2] / eq["r3"] < (3e-4 if prec == 1 else 1e-4)    # the test really is that sharp
+
+
+def test_f64_bit_parity_random_configurations(ps, oracle):
+    """Seeded fuzz over the option space of the fixed-force main (chain type, energy type, field, forces,
+    temperature, monomer length, flips, umbrella, adaptation cadence, generator, chain length, re-inits):
+    every configuration must follow the oracle's trajectory bit for bit."""
+    rng = np.random.default_rng(20260501)
+    for trial in range(80):
+        et = int(rng.choice([0, 0, 2, 1]))
+        n = int(rng.integers(1, 40)) if et != 1 else int(rng.integers(2, 70))
+        kw = dict(n=n, E0=float(rng.uniform(0, 2)), K1=float(rng.uniform(0, 1.2)), K2=float(rng.uniform(0, 0.5)),
+                  mu=float(rng.uniform(0.01, 0.6)), kT=float(10 ** rng.uniform(-0.5, 0.7)), Fz=float(rng.uniform(-1, 2)),
+                  Fx=float(rng.choice([0.0, rng.uniform(-1, 1)])), b=float(rng.uniform(0.5, 2.0)),
+                  chain_type=int(rng.integers(0, 2)), energy_type=et, do_flips=int(rng.integers(0, 2)),
+                  umbrella=int(rng.integers(0, 2)), steps_per_adjust=int(rng.choice([50, 137, 400, 2500])),
+                  adj_scale=float(rng.choice([1.0, 1.1, 1.3])), rng=int(rng.integers(0, 2)), seed=int(rng.integers(0, 2 ** 40)))
+        if et == 2:      # keep the Ising coupling weak: collapsed chains amplify rounding into decisions
+            kw.update(K1=kw["K1"] * 0.3, K2=kw["K2"] * 0.2, mu=kw["mu"] * 0.3)
+        nsteps = 400 if et == 1 else 1200
+        inits = int(rng.choice([1, 1, 2]))
+        force = int(rng.integers(0, 2))
+        op, pp = both(nsteps, num_chains=3, precision=ps.F64, num_inits=inits, force_init=force,
+                      chain_id0=int(rng.integers(0, 2 ** 33)), **kw)
+        with ps.Ensemble(pp) as e:
+            for k in range(inits):
+                e.advance(nsteps)
+                if k + 1 < inits:
+                    e.reinit(bool(force))
+            e.sync()
+            for c in range(3):
+                o = oracle.run(op, chain_id=pp.chain_id0 + c, mode="fast", trace=True)
+                g = e.chain_state(c)
+                assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (trial, kw)
+                assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total, (trial, kw)
+                assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step, (trial, kw)
+                np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-8, atol=1e-8, err_msg=str((trial, kw)))
