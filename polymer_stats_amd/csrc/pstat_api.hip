@@ -35,7 +35,7 @@ int fail(int code, const char *fmt, ...) {
       return fail(PSTAT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));          \
   } while (0)
 
-constexpr uint64_t CKPT_MAGIC = 0x5053544154434b31ull;  // "PSTATCK1"
+constexpr uint64_t CKPT_MAGIC = 0x5053544154434b32ull;  // "PSTATCK2" (v2: 64-bit adaptation windows, two more observables)
 
 struct Buffer {
   void *ptr = nullptr;
@@ -316,7 +316,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_TRY(alloc(h, &S.ang, 2 * n * Cz * h->elem));
   CREATE_TRY(alloc(h, (void **)&S.rng, 4 * Cz * sizeof(uint32_t)));
   CREATE_TRY(alloc(h, (void **)&S.stepsz, 2 * Cz * sizeof(double)));
-  CREATE_TRY(alloc(h, (void **)&S.win, 2 * Cz * sizeof(int32_t)));
+  CREATE_TRY(alloc(h, (void **)&S.win, 2 * Cz * sizeof(int64_t)));
   CREATE_TRY(alloc(h, (void **)&S.nacc_total, Cz * sizeof(int64_t)));
   CREATE_TRY(alloc(h, (void **)&S.obs, NOBS_STATE * Cz * sizeof(double)));
   CREATE_TRY(alloc(h, (void **)&S.sums, NSUMS * Cz * sizeof(double)));
@@ -661,9 +661,9 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sum
     sums[PSTAT_U] = s[S_U]; sums[PSTAT_USQ] = s[S_USQ];
   }
   if (counters) {
-    int32_t w[2];
+    int64_t w[2];
     int64_t tot;
-    HIP_TRY(hipMemcpy2D(w, sizeof(int32_t), h->S.win + chain, C * sizeof(int32_t), sizeof(int32_t), 2,
+    HIP_TRY(hipMemcpy2D(w, sizeof(int64_t), h->S.win + chain, C * sizeof(int64_t), sizeof(int64_t), 2,
                         hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&tot, h->S.nacc_total + chain, sizeof tot, hipMemcpyDeviceToHost));
     counters[0] = tot; counters[1] = h->steps_recorded; counters[2] = w[0]; counters[3] = w[1];

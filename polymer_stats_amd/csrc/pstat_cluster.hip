@@ -120,7 +120,7 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
   g.load(S.rng + c, C);
   double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
   R phistep = (R)(phistep_d / ph_unit), thstep = (R)(thstep_d / th_unit);
-  int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
+  int64_t nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
   R Orx = (R)S.obs[OBS_R1 * C + c], Ory = (R)S.obs[OBS_R2 * C + c], Orz = (R)S.obs[OBS_R3 * C + c];
   R Opx = (R)S.obs[OBS_P1 * C + c], Opy = (R)S.obs[OBS_P2 * C + c], Opz = (R)S.obs[OBS_P3 * C + c];
@@ -424,7 +424,7 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
       to_adj -= chunk;
       if (to_adj == 0) {
         to_adj = spa;
-        const int nacc = nacc_off + nacc_seg, natt = natt_off + steps_seg;
+        const int64_t nacc = nacc_off + nacc_seg, natt = natt_off + steps_seg;
         const double ratio = (double)nacc / (double)natt;
         if (ratio > A.adj_ub && phistep_d != K<double>::pi && thstep_d != K<double>::half_pi) {
           nacc_off = -nacc_seg; natt_off = -steps_seg;

@@ -27,7 +27,8 @@ struct DevState {
   void *ang_tmp;        // R  [2][n][C]   scratch for re-initialisation
   uint32_t *rng;        // u32[4][C]      xoshiro128++ state
   double *stepsz;       // f64[2][C]      phi_step, theta_step (mcmc_eap_chain.jl:172)
-  int32_t *win;         // i32[2][C]      nacc, natt since the last adaptation (:263,265)
+  int64_t *win;         // i64[2][C]      nacc, natt since the last adaptation (:263,265; Int in the reference:
+                        //                a window is never reset while the ratio stays inside the band)
   int64_t *nacc_total;  // i64[C]         (:264)
   double *obs;          // f64[NOBS_STATE][C]  r, p, U, sum(u) of the current microstate
   double *sums;         // f64[NSUMS][C]  averager .value fields (inc/average.jl:9)

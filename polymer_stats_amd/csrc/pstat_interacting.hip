@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void intera
   }
   double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
   R phistep = (R)(phistep_d / AG::unit), thstep = (R)(thstep_d / AG::unit);
-  int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
+  int64_t nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
   R lag = use_lag ? (R)S.lag[c] : (R)0;
   // umbrella sampling (inc/average.jl:104-124), as in the sweep kernel: only w - w(first config) matters
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void intera
       to_adj -= chunk;
       if (to_adj == 0) {
         to_adj = spa;
-        const int nacc = nacc_off + nacc_seg, natt = natt_off + steps_seg;
+        const int64_t nacc = nacc_off + nacc_seg, natt = natt_off + steps_seg;
         const double ratio = (double)nacc / (double)natt;
         if (ratio > A.adj_ub && phistep_d != K<double>::pi && thstep_d != K<double>::half_pi) {
           nacc_off = -nacc_seg; natt_off = -steps_seg;

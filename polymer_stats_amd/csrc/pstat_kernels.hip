@@ -186,7 +186,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   g.load(S.rng + c, C);
   double phistep_d = S.stepsz[0 * C + c], thstep_d = S.stepsz[1 * C + c];
   R phistep = (R)(phistep_d / ph_unit), thstep = (R)(thstep_d / th_unit);
-  int nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
+  int64_t nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
   // observables O = (rx, ry | rz, px | py, pz | U, unused) as four 2-vectors (packed f32 math)
   R O[8];
@@ -446,7 +446,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       to_adj -= chunk;
       if (to_adj == 0) {
         to_adj = spa;
-        const int nacc = nacc_off + nacc_seg, natt = natt_off + steps_seg;
+        const int64_t nacc = nacc_off + nacc_seg, natt = natt_off + steps_seg;
         const double ratio = (double)nacc / (double)natt;
         if (ratio > A.adj_ub && phistep_d != K<double>::pi && thstep_d != K<double>::half_pi) {
           nacc_off = -nacc_seg; natt_off = -steps_seg;
