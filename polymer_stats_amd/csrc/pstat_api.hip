@@ -409,6 +409,12 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
     const int64_t len = nsteps < max_launch ? nsteps : max_launch;
     int nseg = env ? atoi(env) : choose_segments(blocks, h->slots, len);
     if (nseg < 1) nseg = 1;
+    // f32/q16 running totals are re-derived from the angles at every segment start: bound the stretch
+    // over which their rounding errors can random-walk
+    if (h->base.precision != PSTAT_F64 && !env) {
+      const int64_t need = (len + 32767) / 32768;
+      if (need > nseg) nseg = (int)(need < 0x3fffffffLL ? need : 0x3fffffffLL);
+    }
     if (nseg > len) nseg = (int)len;
     if (blocks * nseg > 0x3fffffffLL) nseg = 1;
     h->args.nsteps = len;

@@ -191,6 +191,34 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
                              ma.x, ma.y, ma.z, mb.x, mb.y, mb.z);
     else epair = 0;
   };
+  // f32 keeps r, p, U, sum(u), sum(psi), sum cos^2 as running totals of accepted differences, whose rounding
+  // errors random-walk; at every segment start (<= 32 768 steps apart in f32) they are re-derived from the
+  // angles just filled into LDS (cf. the sweep kernel)
+  auto refresh_totals = [&]() {
+    double tx = 0, ty = 0, tz = 0, qx = 0, qy = 0, qz = 0, tu = 0, tp = 0, tpsi = 0, tc2 = 0;
+    T3 pn{0, 0, 1}, pm{0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+      T3 ni, mi;
+      load_nm(i, ni, mi);
+      tx += (double)ni.x; ty += (double)ni.y; tz += (double)ni.z;
+      qx += (double)mi.x; qy += (double)mi.y; qz += (double)mi.z;
+      tu += (double)(mhalfE0 * mi.z);
+      tc2 += (double)(ni.z * ni.z);
+      if (i > 0) {
+        R psi, eb, ep;
+        bond(pn, pm, ni, mi, psi, eb, ep);
+        tpsi += (double)psi; tu += (double)eb; tp += (double)ep;
+      }
+      pn = ni; pm = mi;
+    }
+    const double bd = (double)b;
+    Orx = (R)(bd * tx); Ory = (R)(bd * ty); Orz = (R)(bd * tz);
+    Opx = (R)qx; Opy = (R)qy; Opz = (R)qz;
+    usum = (R)tu; psisum = (R)tpsi; c2sum = (R)tc2;
+    OU = (R)(tu + tp - ((double)Fx * bd * tx + (double)Fz * bd * tz));
+  };
+
+  if constexpr (sizeof(R) == 4) refresh_totals();
 
   while (left > 0) {
     int chunk = left < FLUSH ? left : FLUSH;

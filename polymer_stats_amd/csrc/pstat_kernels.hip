@@ -227,6 +227,45 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   const P bb = {b, b};
   (void)bb;
 
+  // f32 arithmetic keeps r, p, U as running totals of accepted differences; their rounding errors
+  // random-walk (~3e-6 per accepted move at n = 100).  At every segment start the totals are therefore
+  // re-derived from the angles just filled into LDS, as the reference derives them every step, and
+  // pstat_advance keeps f32 segments at most 32 768 steps long: an O(n) pass costing < 0.1 %.
+  auto refresh_totals = [&]() {
+    double tx = 0, ty = 0, tz = 0, qx = 0, qy = 0, qz = 0, tu = 0, tp = 0;
+    R pnx = 0, pny = 0, pnz = 0, pmx = 0, pmy = 0, pmz = 0;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+      const Cell a = ang[i * lanes + lane];
+      R thi, phi;
+      if constexpr (Q) { thi = q16_theta_turns(a & 0xFFFFu); phi = q16_phi_turns(a >> 16); }
+      else { thi = a.x; phi = a.y; }
+      R si, ci, spi, cpi, mix, miy, miz;
+      AG::sc(thi, &si, &ci);
+      AG::sc(phi, &spi, &cpi);
+      const R nix = cpi * si, niy = spi * si, niz = ci;
+      dipole<R, CT>(a_or_mu, k2e, nix, niy, niz, mix, miy, miz);
+      tx += (double)nix; ty += (double)niy; tz += (double)niz;
+      qx += (double)mix; qy += (double)miy; qz += (double)miz;
+      tu += (double)(mhalfE0 * miz);
+      if constexpr (EN == PSTAT_ISING) {
+        if (i > 0)
+          tp += (double)pair_term_fast(hb * (pnx + nix), hb * (pny + niy), hb * (pnz + niz), pmx, pmy, pmz, mix, miy, miz);
+        pnx = nix; pny = niy; pnz = niz; pmx = mix; pmy = miy; pmz = miz;
+      }
+    }
+    // (each total goes through an opaque register: seen as a group, these assignments make the SLP
+    // vectoriser re-pair the accumulators of the hot loop, which costs it ~10 moves per step)
+    auto opaque = [](R v) __attribute__((always_inline)) -> R { asm volatile("" : "+v"(v)); return v; };
+    const double bd = (double)b;
+    Orxy.x = opaque((R)(bd * tx)); Orxy.y = opaque((R)(bd * ty)); Orz = opaque((R)(bd * tz));
+    Opxy.x = opaque((R)qx); Opxy.y = opaque((R)qy); Opz = opaque((R)qz);
+    usum = opaque((R)tu);
+    OU = opaque((R)(tu + tp - ((double)Fx * bd * tx + (double)Fz * bd * tz)));
+  };
+
+  if constexpr (sizeof(R) == 4) refresh_totals();
+
   while (left > 0) {
     int chunk = left < FLUSH ? left : FLUSH;
     if (A.adaptive && to_adj < chunk) chunk = (int)to_adj;
