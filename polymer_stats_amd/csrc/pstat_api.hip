@@ -429,8 +429,10 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
       h->args.max_spins = (int32_t)(want < 0x7fffffffLL ? want : 0x7fffffffLL);
       if (ms && atoi(ms) > 0) h->args.max_spins = atoi(ms);
     }
-    const int64_t jobs = blocks * nseg;
-    const unsigned grid = (unsigned)(jobs < h->slots ? jobs : h->slots);
+    // Segments of one block run one after the other, so at most `blocks` jobs are runnable at any time:
+    // more workgroups than that would only sit in the predecessor wait -- and, worse, leave the working
+    // ones unevenly spread over the SIMDs.
+    const unsigned grid = (unsigned)(blocks < h->slots ? blocks : h->slots);
     if (h->cfg.move_set == PSTAT_MOVES_CLUSTER)
       HIP_TRY(launch_cluster(h->cfg, h->args, h->S, h->d_cases, h->d_queue, grid, h->stream));
     else
