@@ -4,9 +4,11 @@
  *
  * The reference exposes no FFI for this path: the whole of it lives inside one Julia function,
  * mcmc(nsteps, pargs) (mcmc_eap_chain.jl:171-376), reached only through the command line
- * (mcmc_eap_chain.jl:19-155).  This header is therefore the boundary a maintainer would bind with
- * `ccall` when moving the step loop of that function onto the GPU; each entry point names the
- * reference code it stands in for.  INTEGRATION.md shows the Julia-side binding.
+ * (mcmc_eap_chain.jl:19-155) -- and, for the clustering main, mcmc(nsteps, pargs, chain)
+ * (mcmc_clustering_eap_chain.jl:172-352) under its annealing driver (:354-392).  This header is
+ * therefore the boundary a maintainer would bind with `ccall` when moving the step loop of those
+ * functions onto the GPU; each entry point names the reference code it stands in for.
+ * INTEGRATION.md shows the Julia-side binding.
  *
  * Conventions: plain C, caller-allocated output buffers, no callbacks, no exceptions across the ABI.
  * Every function returns PSTAT_OK (0) or a negative pstat_status; pstat_strerror() names it and
@@ -80,7 +82,7 @@ typedef struct pstat_params {
   uint64_t seed;         /* ours: the reference never seeds its RNG                           */
   uint64_t chain_id0;    /* global id of this handle's first chain: shards over GPUs          */
   int32_t chain_type;    /* PSTAT_DIELECTRIC | PSTAT_POLAR                                    */
-  int32_t energy_type;   /* PSTAT_NONINTERACTING | PSTAT_INTERACTING | PSTAT_ISING            */
+  int32_t energy_type;   /* PSTAT_NONINTERACTING | PSTAT_INTERACTING | PSTAT_ISING | PSTAT_CUTOFF */
   int32_t do_flips;      /* --do-flips                                                        */
   int32_t umbrella;      /* --umbrella-sampling                                               */
   int32_t precision;     /* PSTAT_F32 | PSTAT_F64 | PSTAT_Q16                                 */
@@ -150,6 +152,8 @@ void pstat_destroy(pstat_handle *h);
 /* Replaces `nsteps` iterations of the step loop, mcmc_eap_chain.jl:276-328, for every chain:
  * proposal draw (:277-280), move! (inc/eap_chain.jl:230-257), energy (inc/energy.jl:7-23),
  * Metropolis (inc/acceptance.jl:29-39), step-size adaptation (:301-322), record! x 8 (:327-328).
+ * With move_set = PSTAT_MOVES_CLUSTER: the step loop of mcmc_clustering_eap_chain.jl:268-311 instead
+ * (the same move, then cluster_flip! on the trial chain, Metropolis-Hastings with alpha, record! x 10).
  * Asynchronous on the handle's stream. */
 int pstat_advance(pstat_handle *h, int64_t nsteps);
 int pstat_sync(pstat_handle *h);
@@ -210,8 +214,6 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles /* [2n] */,
                       double sums[PSTAT_NOBS], int64_t counters[4], double steps[3],
                       uint32_t rng[4]);
 
-/* Checkpoint / resume of the full device state (angles, generators, step sizes, counters, running
- * sums).  Call with buf == NULL to get the size.  The reference has no equivalent (SURVEY 5). */
 /* Start every chain over from a given configuration, as EAPChain(pargs) does with --x0/--dx0
  * (inc/eap_chain.jl:61-79): x0 holds [phi; theta] (len 2: every monomer) or the interleaved
  * [phi1, theta1, phi2, theta2, ...] (len 2n); each angle gets + Uniform(0, dx0).  Generators are
@@ -221,6 +223,9 @@ int pstat_restart_from_x0(pstat_handle *h, const double *x0, int64_t len, double
 /* The clustering main's two extra averagers for one chain: their running sums and their value in
  * the current configuration (sum cos^2 theta; mean bond angle). */
 int pstat_chain_extras(pstat_handle *h, int64_t chain, double extra_sums[2], double extra_now[2]);
+
+/* Checkpoint / resume of the full device state (angles, generators, step sizes, counters, running
+ * sums).  Call with buf == NULL to get the size.  The reference has no equivalent (SURVEY 5). */
 int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes);
 int pstat_restore(pstat_handle *h, const void *buf, size_t bytes);
 
