@@ -76,12 +76,30 @@ def cpu_baseline(n, mc_steps, target_seconds=12.0):
     nchains = cores * per_thread
     log(f"cpu baseline: {cores} threads x {per_thread} chains, one chain takes {one:.3f} s")
     t0 = time.perf_counter()
-    ob.run_many(P, id0=1, nchains=nchains, nthreads=cores, mode="faithful")
+    sums, norm, _ = ob.run_many(P, id0=1, nchains=nchains, nthreads=cores, mode="faithful")
     wall = time.perf_counter() - t0
+    m = sums / norm[:, None]
+    mean, se = m.mean(axis=0), m.std(axis=0, ddof=1) / max(1.0, float(nchains)) ** 0.5
     return {"value": nchains * mc_steps / wall, "unit": "MC monomer-updates/s", "cores": cores,
             "kind": "port",
             "sample": f"{nchains} chains x {mc_steps} steps, n={n}, Fz=1, oracle faithful mode (deep copy + "
-                      f"full recompute per step, fp64, one thread per chain), {wall:.1f} s wall"}
+                      f"full recompute per step, fp64, one thread per chain), {wall:.1f} s wall"}, mean, se
+
+
+def parity_vs_cpu(ps, prec, n, chains, mc_steps, device, cpu_mean, cpu_se):
+    """The north star's acceptance line: <r_z>, <p_z>, <U> of the device path against the CPU restatement run
+    under the same options and protocol (same Fz = 1 point, same number of steps, no burn-in on either
+    side), as z = (gpu - cpu) / sqrt(se_gpu^2 + se_cpu^2).  One extra untimed launch."""
+    p = ps.default_params(n=n, E0=1.0, K1=1.0, K2=0.0, kT=1.0, b=1.0, Fz=1.0, num_chains=chains, seed=20260499,
+                          precision=prec, device=device)
+    with ps.Ensemble(p) as e:
+        e.advance(mc_steps)
+        s = e.summary()
+    out = {}
+    for name, k in (("r3", 2), ("p3", 9), ("U", 14)):
+        z = (s.avg[k] - cpu_mean[k]) / ((s.stderr[k] ** 2 + cpu_se[k] ** 2) ** 0.5 + 1e-300)
+        out[name] = {"gpu": s.avg[k], "cpu": float(cpu_mean[k]), "z": float(z)}
+    return out
 
 
 def main():
@@ -244,7 +262,9 @@ def main():
                       "chains_pooled": int(last.num_chains)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.n, args.mc_steps)
+            base, cpu_mean, cpu_se = cpu_baseline(args.n, args.mc_steps)
+            base["parity"] = parity_vs_cpu(ps, prec, args.n, args.chains, args.mc_steps, local_rank, cpu_mean, cpu_se)
+            out["cpu_baseline"] = base
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     for e in ens:
         e.close()
