@@ -98,3 +98,25 @@ def test_clustering_cli_outputs_and_oracle(tmp_path, oracle):
     z = (got - m.mean(0)) / (se * 1.1 + 1e-12)
     assert np.all(np.abs(z) < 4.5), z
     assert abs(float(vals["AR"]) - nacc.mean() / N) < 0.01
+
+
+def test_cli_device_sharding_is_invisible(tmp_path):
+    """--devices shards the chains by global chain id over several handles and merges their additive reduction
+    vectors on the host: the same job on one handle or split over two (here both on device 0) prints the
+    same numbers."""
+    from polymer_stats_amd import mcmc_eap_chain as host
+    outs = []
+    for tag, dev in (("a", "0"), ("b", "0,0")):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            host.main(["-n", "30", "-e", "1.0", "-F", "0.6", "-N", "4000", "-s", "2000", "-v", "0", "--num-chains", "1000",
+                       "--seed", "12", "--devices", dev, "--precision", "f64", "--prefix", str(tmp_path / tag)])
+        outs.append({l.split("=")[0].strip(): np.array(eval(l.split("=")[1]), dtype=float)
+                     for l in buf.getvalue().strip().splitlines()})
+    for k in outs[0]:
+        np.testing.assert_allclose(outs[1][k], outs[0][k], rtol=1e-11, atol=1e-12, err_msg=k)
+    ra = open(tmp_path / "a_rolling.csv").read().splitlines()
+    rb = open(tmp_path / "b_rolling.csv").read().splitlines()
+    assert len(ra) == len(rb) == 3
+    np.testing.assert_allclose([float(x) for x in rb[-1].split(",")], [float(x) for x in ra[-1].split(",")], rtol=1e-11, atol=1e-12)
+    assert open(tmp_path / "a_trajectory.csv").read() == open(tmp_path / "b_trajectory.csv").read()   # chain 0 is chain 0
