@@ -5,7 +5,7 @@
  * The reference exposes no FFI for this path: the whole of it lives inside one Julia function,
  * mcmc(nsteps, pargs) (mcmc_eap_chain.jl:171-376), reached only through the command line
  * (mcmc_eap_chain.jl:19-155) -- and, for the clustering main, mcmc(nsteps, pargs, chain)
- * (mcmc_clustering_eap_chain.jl:172-352) under its annealing driver (:354-392).  This header is
+ * (mcmc_clustering_eap_chain.jl:172-352) under its annealing driver (:354-387).  This header is
  * therefore the boundary a maintainer would bind with `ccall` when moving the step loop of those
  * functions onto the GPU; each entry point names the reference code it stands in for.
  * INTEGRATION.md shows the Julia-side binding.

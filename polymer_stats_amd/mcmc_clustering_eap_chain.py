@@ -28,7 +28,7 @@ from . import _lib
 from .julia_fmt import jl_float, jl_row, jl_vector
 from .mcmc_eap_chain import Averager, ReferenceError_, _Pool, _log, get_avg
 
-ROLL_HEADER = "step,r1,r2,r3,r1sq,r2sq,r3sq,rsq,p1,p2,p3,p1sq,p2sq,p3sq,psq,U,Usq,Ealign,psi"   # :257
+ROLL_HEADER = "step,r1,r2,r3,r1sq,r2sq,r3sq,rsq,p1,p2,p3,p1sq,p2sq,p3sq,psq,U,Usq,Ealign,psi"   # :259
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -157,7 +157,7 @@ def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int)
 
 
 def traj_header(n: int) -> str:
-    """mcmc_clustering_eap_chain.jl:250-254: phi/theta interleaved per monomer, then mux/muy/muz."""
+    """mcmc_clustering_eap_chain.jl:253-258: phi/theta interleaved per monomer, then mux/muy/muz."""
     cols = ["step", "r1", "r2", "r3", "p1", "p2", "p3", "U"]
     for i in range(1, n + 1):
         cols += [f"phi{i}", f"theta{i}"]
@@ -200,7 +200,7 @@ def _stage(pool, nsteps, pargs, kT, write: bool):
                 _log(pargs, 3, "Info", f"elapsed: {time.time() - start}")
                 _log(pargs, 3, "Info", f"step:    {step} / {nsteps}")
                 last_update = time.time()
-            if write and stepout > 0 and step % stepout == 0:           # :312-340
+            if write and stepout > 0 and step % stepout == 0:           # :312-335
                 micro = pool.microstate()
                 st = pool.chain0()
                 mus = _dipoles(pargs, st["phi"], st["theta"])
@@ -219,7 +219,7 @@ def _stage(pool, nsteps, pargs, kT, write: bool):
 
 
 def run(pargs: dict):
-    """The top level of mcmc_clustering_eap_chain.jl:354-392 -> (scalar_averagers, vector_averagers, ar)."""
+    """The top level of mcmc_clustering_eap_chain.jl:354-387 -> (scalar_averagers, vector_averagers, ar)."""
     if pargs["numeric-type"] not in ("float64", "float128", "dec128", "big"):
         raise ReferenceError_(f"numeric-type '{pargs['numeric-type']}' not understood")    # :191
     if pargs["numeric-type"] != "float64":
@@ -251,7 +251,7 @@ def run(pargs: dict):
 
 
 def summary_lines(sas, vas, ar, pargs) -> list[str]:
-    """The twelve println lines, mcmc_clustering_eap_chain.jl:394-405."""
+    """The twelve println lines, mcmc_clustering_eap_chain.jl:389-400."""
     nb = pargs["mlen"] * pargs["num-monomers"]
     return [
         f"<r>    =   {jl_vector(get_avg(vas[0]))}",

@@ -61,7 +61,7 @@ def test_cli_multi_init_and_umbrella_run(tmp_path):
 
 def test_clustering_cli_outputs_and_oracle(tmp_path, oracle):
     """The clustering main end to end: burn-in ladder, twelve stdout lines, the two CSV files with the
-    clustering main's extra columns (mcmc_clustering_eap_chain.jl:250-257,312-340,394-405); numbers
+    clustering main's extra columns (mcmc_clustering_eap_chain.jl:253-259,312-335,389-400); numbers
     against the oracle's literal restatement run under the same options."""
     from polymer_stats_amd import mcmc_clustering_eap_chain as host
     prefix = str(tmp_path / "cl")
