@@ -195,8 +195,9 @@ def run(params: EapParams, chain_id: int = 0, mode: str = "faithful", trace: boo
     return out
 
 
-def run_many(params: EapParams, id0: int, nchains: int, nthreads: int = 1, mode: str = "fast"):
-    """Returns (sums[nchains,16], norm[nchains], nacc[nchains]) for chain ids id0..id0+nchains-1."""
+def run_many(params: EapParams, id0: int, nchains: int, nthreads: int = 1, mode: str = "fast", extras: bool = False):
+    """Returns (sums[nchains,16], norm[nchains], nacc[nchains]) for chain ids id0..id0+nchains-1
+    (+ extra_sums[nchains,2], the clustering main's two more averagers, if `extras`)."""
     L = lib()
     arr = (EapResult * nchains)()
     rc = L.eap_run_many(C.byref(params), id0, nchains, nthreads, {"faithful": 0, "fast": 1, "cluster": 2}[mode], arr)
@@ -205,6 +206,8 @@ def run_many(params: EapParams, id0: int, nchains: int, nthreads: int = 1, mode:
     sums = np.array([a.sum[:] for a in arr])
     norm = np.array([a.norm for a in arr])
     nacc = np.array([a.nacc_total for a in arr])
+    if extras:
+        return sums, norm, nacc, np.array([a.extra_sum[:] for a in arr])
     return sums, norm, nacc
 
 

@@ -17,23 +17,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NCHAINS, NSTEPS = 24, 3000
 
 
-def reduction_vector(sums, norm, nacc, steps):
-    # 16 observables, acceptance ratio, and the clustering main's two extras (zero in this main)
-    m = np.concatenate([sums / norm[:, None], (nacc / steps)[:, None], np.zeros((len(norm), 2))], axis=1)
+def reduction_vector(sums, norm, nacc, steps, extra):
+    # 16 observables, acceptance ratio, and the clustering main's two extras (zero in the first main)
+    m = np.concatenate([sums / norm[:, None], (nacc / steps)[:, None], extra / norm[:, None]], axis=1)
     return np.concatenate([[m.shape[0]], m.sum(0), (m ** 2).sum(0)])
 
 
-def worker(rank, world, port, out):
+def job(ob, mode):
+    if mode == "cluster":
+        return ob.make_params(n=10, E0=1.0, K1=1.0, Fz=0.5, num_steps=NSTEPS, seed=5, cluster_prob=0.5, bend_mod=0.4,
+                              burn_in=500, burn_sched=[10.0, 1.0])
+    return ob.make_params(n=10, E0=1.0, K1=1.0, Fz=0.5, num_steps=NSTEPS, seed=5)
+
+
+def worker(rank, world, port, out, mode):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import binding as ob
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    P = ob.make_params(n=10, E0=1.0, K1=1.0, Fz=0.5, num_steps=NSTEPS, seed=5)
     per = NCHAINS // world
-    sums, norm, nacc = ob.run_many(P, rank * per, per, nthreads=2, mode="fast")   # shard by global chain id
-    red = torch.from_numpy(reduction_vector(sums, norm, nacc, NSTEPS))
+    sums, norm, nacc, extra = ob.run_many(job(ob, mode), rank * per, per, nthreads=2, mode=mode, extras=True)   # shard by global chain id
+    red = torch.from_numpy(reduction_vector(sums, norm, nacc, NSTEPS, extra))
     dist.all_reduce(red)                                                          # the one collective
     if rank == 0:
         np.save(out, red.numpy())
@@ -41,20 +47,23 @@ def worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_merge_equals_single_process(tmp_path, oracle):
+@pytest.mark.parametrize("mode", ["fast", "cluster"])
+def test_two_rank_merge_equals_single_process(tmp_path, oracle, mode):
     import polymer_stats_amd as ps
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "red.npy")
-    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(worker, args=(2, port, out, mode), nprocs=2, join=True)
     merged = np.load(out)
-    P = oracle.make_params(n=10, E0=1.0, K1=1.0, Fz=0.5, num_steps=NSTEPS, seed=5)
-    sums, norm, nacc = oracle.run_many(P, 0, NCHAINS, nthreads=4, mode="fast")
-    single = reduction_vector(sums, norm, nacc, NSTEPS)
+    sums, norm, nacc, extra = oracle.run_many(job(oracle, mode), 0, NCHAINS, nthreads=4, mode=mode, extras=True)
+    single = reduction_vector(sums, norm, nacc, NSTEPS, extra)
     np.testing.assert_allclose(merged, single, rtol=1e-12)
     s = ps.summary_from_reduction(merged, NSTEPS)
     m = sums / norm[:, None]
     np.testing.assert_allclose(np.array(s.avg), m.mean(0), rtol=1e-12)
     np.testing.assert_allclose(np.array(s.stderr), m.std(0, ddof=1) / np.sqrt(NCHAINS), rtol=1e-8)
     assert s.num_chains == NCHAINS
+    np.testing.assert_allclose(np.array(s.extra_avg), (extra / norm[:, None]).mean(0), rtol=1e-12, atol=1e-300)
+    if mode == "cluster":
+        assert s.extra_avg[0] > 0 and 0 < s.extra_avg[1] < np.pi       # <sum cos^2 theta>, <psi>
