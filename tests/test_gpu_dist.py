@@ -1,0 +1,56 @@
+"""N > 1 on the GPU box: two processes (gloo, both on device 0) each own a shard of the chains by global
+chain id, advance it with libpstat, reduce on the device and merge with ONE all-reduce(SUM) of the 39-double
+vector -- the data path of bench.py --gpus N with gloo standing in for RCCL.  The merged summary must equal
+the one of a single handle holding all chains (chains are identified by id, not by owner)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NCHAINS, NSTEPS = 512, 3000
+KW = dict(n=30, E0=1.0, K1=1.0, K2=0.1, Fz=0.6, seed=91)
+
+
+def worker(rank, world, port, out, moves):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import polymer_stats_amd as ps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = NCHAINS // world
+    p = ps.default_params(num_chains=per, chain_id0=rank * per, precision=ps.F64, move_set=moves, **KW)
+    with ps.Ensemble(p) as e:
+        e.advance(NSTEPS)
+        red = torch.from_numpy(e.reduce_host())
+    dist.all_reduce(red)
+    if rank == 0:
+        np.save(out, red.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("moves", [0, 1])
+def test_two_ranks_on_one_gpu_merge_to_the_single_handle_result(tmp_path, moves):
+    import torch.multiprocessing as mp
+    import polymer_stats_amd as ps
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "red.npy")
+    mp.spawn(worker, args=(2, port, out, moves), nprocs=2, join=True)
+    merged = ps.summary_from_reduction(np.load(out), NSTEPS)
+    with ps.Ensemble(ps.default_params(num_chains=NCHAINS, precision=ps.F64, move_set=moves, **KW)) as e:
+        e.advance(NSTEPS)
+        single = e.summary()
+    assert merged.num_chains == single.num_chains == NCHAINS
+    np.testing.assert_allclose(np.array(merged.avg), np.array(single.avg), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(np.array(merged.stderr), np.array(single.stderr), rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(np.array(merged.extra_avg), np.array(single.extra_avg), rtol=1e-11, atol=1e-12)
+    assert merged.acceptance_ratio == pytest.approx(single.acceptance_ratio, rel=1e-12)
