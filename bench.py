@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--mc-steps", type=int, default=100000, help="MC steps per chain per bench step")
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--precision", choices=["f32", "f64", "q16"], default="f32")
+    ap.add_argument("--rng", choices=["mwc64x", "xoshiro128++"], default="mwc64x",
+                    help="per-chain generator (default MWC64X; xoshiro128++ is the north star's named one, measured slower here)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -168,7 +170,8 @@ def main():
         for i in range(nstep_total):
             p = ps.default_params(n=args.n, E0=1.0, K1=1.0, K2=0.0, kT=1.0, b=1.0, Fz=FZ_SWEEP[i % len(FZ_SWEEP)],
                                   num_chains=args.chains, chain_id0=rank * args.chains,
-                                  seed=20260501 + i, precision=prec, device=local_rank)
+                                  seed=20260501 + i, precision=prec, device=local_rank,
+                                  rng=ps.RNG_XOSHIRO128PP if args.rng == "xoshiro128++" else ps.RNG_MWC64X)
             ens.append(ps.Ensemble(p, stream=stream.cuda_stream))
         info = ens[0].launch_info()
         log(f"rank {rank}: {nstep_total} ensembles ready; kernel {info.kernel.decode()} lds={info.lds_bytes} "
@@ -246,7 +249,7 @@ def main():
                                    % (args.n, args.chains, args.mc_steps),
                        "chains_per_gpu": args.chains, "mc_steps_per_chain": args.mc_steps, "n": args.n,
                        "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-reduce of {ps.NRED} doubles per step",
-                       "kernel": info.kernel.decode(), "lds_bytes_per_wg": info.lds_bytes,
+                       "kernel": info.kernel.decode(), "rng": args.rng, "lds_bytes_per_wg": info.lds_bytes,
                        "workgroups": int(info.blocks), "wg_per_cu_resident": info.blocks_per_cu},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
