@@ -29,7 +29,7 @@
 #include "pstat_math.h"
 
 #ifndef PSTAT_UNROLL
-#define PSTAT_UNROLL 8   // steps per basic block of the sweep loop (even)
+#define PSTAT_UNROLL 16  // steps per basic block of the sweep loop (even; measured: 8 -> 16 +1.2 %, 32 -4 %)
 #endif
 
 namespace pstat {
