@@ -520,18 +520,32 @@ ClusterFn pick_ct_en(const LaunchCfg &cfg) {
                : cluster_kernel<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING, ST>;
 }
 
-ClusterFn pick_cluster(const LaunchCfg &cfg) {
+}  // namespace
+
+// Two objects are built from this file (csrc/Makefile): -DPSTAT_CPART=1 holds the f32 and q16 instantiations
+// and is compiled with -ffp-contract=fast (statistical parity only), -DPSTAT_CPART=2 the f64 ones and the
+// launchers with -ffp-contract=off (bit parity with the oracle).  Without the macro: everything in one object.
+#if !defined(PSTAT_CPART) || PSTAT_CPART == 1
+ClusterFn pick_cluster_f32(const LaunchCfg &cfg) {
   const bool xo = cfg.rng == PSTAT_RNG_XOSHIRO128PP;
-  if (cfg.precision == PSTAT_F64) return xo ? pick_ct_en<double, Xoshiro128pp, 0>(cfg) : pick_ct_en<double, Mwc64x, 0>(cfg);
   if (cfg.precision == PSTAT_Q16) return xo ? pick_ct_en<float, Xoshiro128pp, 1>(cfg) : pick_ct_en<float, Mwc64x, 1>(cfg);
   return xo ? pick_ct_en<float, Xoshiro128pp, 0>(cfg) : pick_ct_en<float, Mwc64x, 0>(cfg);
 }
+#endif
+#if !defined(PSTAT_CPART) || PSTAT_CPART == 2
+ClusterFn pick_cluster_f32(const LaunchCfg &cfg);
 
-int cluster_lds_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
-  return (int)(a.n * a.lanes * (cfg.precision == PSTAT_F64 ? 16 : (cfg.precision == PSTAT_Q16 ? 4 : 8)));
+ClusterFn pick_cluster_f64(const LaunchCfg &cfg) {
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_ct_en<double, Xoshiro128pp, 0>(cfg) : pick_ct_en<double, Mwc64x, 0>(cfg);
 }
 
-}  // namespace
+static ClusterFn pick_cluster(const LaunchCfg &cfg) {
+  return cfg.precision == PSTAT_F64 ? pick_cluster_f64(cfg) : pick_cluster_f32(cfg);
+}
+
+static int cluster_lds_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
+  return (int)(a.n * a.lanes * (cfg.precision == PSTAT_F64 ? 16 : (cfg.precision == PSTAT_Q16 ? 4 : 8)));
+}
 
 hipError_t cluster_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes, int *blocks_per_cu,
                                const char **name) {
@@ -560,5 +574,6 @@ hipError_t launch_cluster(const LaunchCfg &cfg, const SweepArgs &a, const DevSta
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a, s, cases, cfg.umbrella, queue);
   return hipGetLastError();
 }
+#endif
 
 }  // namespace pstat
