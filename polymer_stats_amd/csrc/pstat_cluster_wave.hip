@@ -332,28 +332,38 @@ __global__ __launch_bounds__(64) void cluster_wave_kernel(SweepArgs A, DevState 
 
 using WaveFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int);
 
-template <typename G, int M>
-WaveFn pick_gm(const LaunchCfg &cfg) {
+template <typename R, typename G>
+WaveFn pick_m(const LaunchCfg &cfg, int64_t n) {
   const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
-  if (cfg.precision == PSTAT_F64)
-    return diel ? cluster_wave_kernel<double, G, PSTAT_DIELECTRIC, M> : cluster_wave_kernel<double, G, PSTAT_POLAR, M>;
-  return diel ? cluster_wave_kernel<float, G, PSTAT_DIELECTRIC, M> : cluster_wave_kernel<float, G, PSTAT_POLAR, M>;
-}
-template <typename G>
-WaveFn pick_g(const LaunchCfg &cfg, int64_t n) {
-  if (n <= 64) return pick_gm<G, 1>(cfg);
-  if (n <= 128) return pick_gm<G, 2>(cfg);
-  if (n <= 256) return pick_gm<G, 4>(cfg);
-  // 8 monomers per lane (n <= 512; the reference's only cutoff-energy sweep, run/phases-big_2023-05-18.jl, uses
-  // n = 400): f32 only -- in f64 two configurations of 8 monomers per lane do not fit the register file
-  const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
-  return diel ? cluster_wave_kernel<float, G, PSTAT_DIELECTRIC, 8> : cluster_wave_kernel<float, G, PSTAT_POLAR, 8>;
-}
-WaveFn pick_wave(const LaunchCfg &cfg, int64_t n) {
-  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_g<Xoshiro128pp>(cfg, n) : pick_g<Mwc64x>(cfg, n);
+  if (n <= 64) return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 1> : cluster_wave_kernel<R, G, PSTAT_POLAR, 1>;
+  if (n <= 128) return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 2> : cluster_wave_kernel<R, G, PSTAT_POLAR, 2>;
+  if constexpr (sizeof(R) == 8) {
+    return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 4> : cluster_wave_kernel<R, G, PSTAT_POLAR, 4>;
+  } else {
+    if (n <= 256) return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 4> : cluster_wave_kernel<R, G, PSTAT_POLAR, 4>;
+    // 8 monomers per lane (n <= 512; the reference's only cutoff-energy sweep, run/phases-big_2023-05-18.jl, uses
+    // n = 400): f32 only -- in f64 two configurations of 8 monomers per lane do not fit the register file
+    return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 8> : cluster_wave_kernel<R, G, PSTAT_POLAR, 8>;
+  }
 }
 
 }  // namespace
+
+// Two objects are built from this file (csrc/Makefile): -DPSTAT_WPART=1 holds the f32 instantiations, compiled
+// with -ffp-contract=fast (statistical parity only); -DPSTAT_WPART=2 the f64 ones and the launchers with
+// -ffp-contract=off (bit parity with the oracle).  Without the macro: everything in one object.
+#if !defined(PSTAT_WPART) || PSTAT_WPART == 1
+WaveFn pick_wave_f32(const LaunchCfg &cfg, int64_t n) {
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_m<float, Xoshiro128pp>(cfg, n) : pick_m<float, Mwc64x>(cfg, n);
+}
+#endif
+#if !defined(PSTAT_WPART) || PSTAT_WPART == 2
+WaveFn pick_wave_f32(const LaunchCfg &cfg, int64_t n);
+
+static WaveFn pick_wave(const LaunchCfg &cfg, int64_t n) {
+  if (cfg.precision != PSTAT_F64) return pick_wave_f32(cfg, n);
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_m<double, Xoshiro128pp>(cfg, n) : pick_m<double, Mwc64x>(cfg, n);
+}
 
 hipError_t launch_cluster_wave(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s, const CaseConst *cases,
                                hipStream_t stream) {
@@ -372,5 +382,6 @@ hipError_t cluster_wave_kernel_info(const LaunchCfg &cfg, int64_t n, int *blocks
   if (name) *name = cfg.precision == PSTAT_F64 ? "cluster_wave_kernel<double>" : "cluster_wave_kernel<float>";
   return hipSuccess;
 }
+#endif
 
 }  // namespace pstat
