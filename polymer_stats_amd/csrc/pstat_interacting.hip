@@ -342,21 +342,30 @@ __global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void intera
 
 using InterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int, int, int);
 
-template <typename G, int M>
-static InterFn pick_interacting_gm(const LaunchCfg &cfg) {
+template <typename R, typename G>
+static InterFn pick_interacting_m(const LaunchCfg &cfg, int64_t n) {
   const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
-  if (cfg.precision == PSTAT_F64)
-    return diel ? interacting_kernel<double, G, PSTAT_DIELECTRIC, M> : interacting_kernel<double, G, PSTAT_POLAR, M>;
-  return diel ? interacting_kernel<float, G, PSTAT_DIELECTRIC, M> : interacting_kernel<float, G, PSTAT_POLAR, M>;
+  if (n <= 64) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 1> : interacting_kernel<R, G, PSTAT_POLAR, 1>;
+  if (n <= 128) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 2> : interacting_kernel<R, G, PSTAT_POLAR, 2>;
+  return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 4> : interacting_kernel<R, G, PSTAT_POLAR, 4>;
 }
-template <typename G>
-static InterFn pick_interacting_g(const LaunchCfg &cfg, int64_t n) {
-  if (n <= 64) return pick_interacting_gm<G, 1>(cfg);
-  if (n <= 128) return pick_interacting_gm<G, 2>(cfg);
-  return pick_interacting_gm<G, 4>(cfg);
+
+// Two objects are built from this file (csrc/Makefile): -DPSTAT_IPART=1 holds the f32 instantiations, compiled
+// with -ffp-contract=fast (statistical parity only); -DPSTAT_IPART=2 the f64 ones and the launchers with
+// -ffp-contract=off (bit parity with the oracle).  Without the macro: everything in one object.
+#if !defined(PSTAT_IPART) || PSTAT_IPART == 1
+InterFn pick_interacting_f32(const LaunchCfg &cfg, int64_t n) {
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_interacting_m<float, Xoshiro128pp>(cfg, n)
+                                           : pick_interacting_m<float, Mwc64x>(cfg, n);
 }
+#endif
+#if !defined(PSTAT_IPART) || PSTAT_IPART == 2
+InterFn pick_interacting_f32(const LaunchCfg &cfg, int64_t n);
+
 static InterFn pick_interacting(const LaunchCfg &cfg, int64_t n) {
-  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_interacting_g<Xoshiro128pp>(cfg, n) : pick_interacting_g<Mwc64x>(cfg, n);
+  if (cfg.precision != PSTAT_F64) return pick_interacting_f32(cfg, n);
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_interacting_m<double, Xoshiro128pp>(cfg, n)
+                                           : pick_interacting_m<double, Mwc64x>(cfg, n);
 }
 
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
@@ -376,5 +385,6 @@ hipError_t interacting_kernel_info(const LaunchCfg &cfg, int64_t n, int *blocks_
   if (name) *name = cfg.precision == PSTAT_F64 ? "interacting_kernel<double>" : "interacting_kernel<float>";
   return hipSuccess;
 }
+#endif
 
 }  // namespace pstat
