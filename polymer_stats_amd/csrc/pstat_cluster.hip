@@ -305,7 +305,7 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
         bool gu = hasR, gl = hasL;
         int rowu = min(idx + 2, n - 1), rowl = max(idx - 2, 0);
         Cell au = ang[rowu * lanes + lane], al = ang[rowl * lanes + lane];
-        while (gu || gl) {
+        auto round = [&]() __attribute__((always_inline)) {
           T3 Cu, Cl;
           const bool eCu = nhat_of(dec(au), Cu), eCl = nhat_of(dec(al), Cl);
           rowu = min(rowu + 1, n - 1); rowl = max(rowl - 1, 0);
@@ -334,7 +334,10 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
             gl = acc && lower > 0;
             Al = Bl; Bl = Cl; eBl = eCl;
           }
-        }
+        };
+        // two rounds per trip: the body is branch-free (a finished end neither draws nor moves), so the second
+        // round is harmless when everything stopped in the first, and the loop test is paid half as often
+        while (gu || gl) { round(); round(); }
         upper_p = upper >= n - 1 ? (R)0 : upper_p;   // ran into the chain end: no link to test, :282-284
         lower_p = lower <= 0 ? (R)0 : lower_p;       // :299-301
         // the two boundary bonds, before and after the reflection (:318-326); their monomers are read
