@@ -258,23 +258,24 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
       dipole<R, CT>(a_or_mu, k2e, n0.x, n0.y, n0.z, m0.x, m0.y, m0.z);
       dipole<R, CT>(a_or_mu, k2e, n1.x, n1.y, n1.z, m1.x, m1.y, m1.z);
       const bool hasL = idx > 0, hasR = idx + 1 < n;
-      T3 nL{0, 0, 1}, mL{0, 0, 0}, nR{0, 0, 1}, mR{0, 0, 0};
-      bool edgeL = false, edgeR = false;
-      if (hasL) edgeL = load_nm(idx - 1, nL, mL);
-      if (hasR) edgeR = load_nm(idx + 1, nR, mR);
+      // the two neighbours, branch-free: at a chain end the clamped index re-reads the monomer itself and the
+      // bond's contributions are masked out
+      T3 nL, mL, nR, mR;
+      const bool edgeL = load_nm(max(idx - 1, 0), nL, mL) && hasL;
+      const bool edgeR = load_nm(min(idx + 1, n - 1), nR, mR) && hasR;
       const R du_field = mhalfE0 * (m1.z - m0.z);
       R dpsi = 0, dbend = 0, dpair = 0;
-      if (hasL) {
+      {
         R p0, e0, q0, p1, e1, q1;
         bond(nL, mL, n0, m0, p0, e0, q0);
         bond(nL, mL, n1, m1, p1, e1, q1);
-        dpsi += p1 - p0; dbend += e1 - e0; dpair += q1 - q0;
+        dpsi += hasL ? p1 - p0 : (R)0; dbend += hasL ? e1 - e0 : (R)0; dpair += hasL ? q1 - q0 : (R)0;
       }
-      if (hasR) {
+      {
         R p0, e0, q0, p1, e1, q1;
         bond(n0, m0, nR, mR, p0, e0, q0);
         bond(n1, m1, nR, mR, p1, e1, q1);
-        dpsi += p1 - p0; dbend += e1 - e0; dpair += q1 - q0;
+        dpsi += hasR ? p1 - p0 : (R)0; dbend += hasR ? e1 - e0 : (R)0; dpair += hasR ? q1 - q0 : (R)0;
       }
 
       // ---- cluster_flip!(trial, idx), inc/eap_chain.jl:269-333
