@@ -287,9 +287,12 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
       int upper = idx, lower = idx;
       R drz_flip = 0, du_flip = 0, dpair_flip = 0, dpsi_flip = 0;
       T3 dp_flip{0, 0, 0};
-      if (!(u01<R>(g.next()) <= cprob)) {                                   // :276
-        flipped = true;
-        edge = th1 == (R)0 || th1 == AG::theta_max;
+      // (the region below is predicated by `flipped`, not branched around: with ~50 lanes some lane flips in
+      // practically every step, so the wave runs it anyway, and without the branch the scheduler can overlap
+      // it with the single-move arithmetic)
+      flipped = !(u01<R>(g.next()) <= cprob);                               // :276
+      if (__builtin_amdgcn_ballot_w64(flipped) != 0) {     // wave-uniform: skipped only if no lane flips at all
+        edge = flipped && (th1 == (R)0 || th1 == AG::theta_max);
         R snz = n1.z;                 // sums over the members (the moved monomer enters as proposed)
         T3 sm = m1;
         R upper_p = 0, lower_p = 0, new_upper_p = 0, new_lower_p = 0;
@@ -303,7 +306,7 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
         // predicated state is the generator, the extents, the member sums and the clamp flag.
         T3 Au = n1, Bu = nR, Al = n1, Bl = nL;
         bool eBu = edgeR, eBl = edgeL;
-        bool gu = hasR, gl = hasL;
+        bool gu = flipped && hasR, gl = flipped && hasL;
         int rowu = min(idx + 2, n - 1), rowl = max(idx - 2, 0);
         Cell au = ang[rowu * lanes + lane], al = ang[rowl * lanes + lane];
         auto round = [&]() __attribute__((always_inline)) {
@@ -349,33 +352,41 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
           load_nm(min(upper + 1, n - 1), nu, num);
           load_nm(lower, cl, clm);
           load_nm(max(lower - 1, 0), nl, nlm);
-          if (upper == idx) { cu = n1; cum = m1; }
-          if (lower == idx) { cl = n1; clm = m1; }
-          if (upper < n - 1) {
+          const bool selfu = upper == idx, selfl = lower == idx;
+          cu.x = selfu ? n1.x : cu.x; cu.y = selfu ? n1.y : cu.y; cu.z = selfu ? n1.z : cu.z;
+          cum.x = selfu ? m1.x : cum.x; cum.y = selfu ? m1.y : cum.y; cum.z = selfu ? m1.z : cum.z;
+          cl.x = selfl ? n1.x : cl.x; cl.y = selfl ? n1.y : cl.y; cl.z = selfl ? n1.z : cl.z;
+          clm.x = selfl ? m1.x : clm.x; clm.y = selfl ? m1.y : clm.y; clm.z = selfl ? m1.z : clm.z;
+          {
+            const bool on = flipped && upper < n - 1;
             const T3 rf = refl_n(cu), rfm = refl_mu(cum);
             R p0, e0, q0, p1, e1, q1;
             bond(cu, cum, nu, num, p0, e0, q0);
             bond(rf, rfm, nu, num, p1, e1, q1);
-            new_upper_p = (1 + dot3(rf, nu)) / 2;
-            dpsi_flip += p1 - p0; du_flip += e1 - e0; dpair_flip += q1 - q0;
+            new_upper_p = on ? (1 + dot3(rf, nu)) / 2 : (R)0;
+            dpsi_flip += on ? p1 - p0 : (R)0; du_flip += on ? e1 - e0 : (R)0; dpair_flip += on ? q1 - q0 : (R)0;
           }
-          if (lower > 0) {
+          {
+            const bool on = flipped && lower > 0;
             const T3 rf = refl_n(cl), rfm = refl_mu(clm);
             R p0, e0, q0, p1, e1, q1;
             bond(nl, nlm, cl, clm, p0, e0, q0);
             bond(nl, nlm, rf, rfm, p1, e1, q1);
-            new_lower_p = (1 + dot3(rf, nl)) / 2;
-            dpsi_flip += p1 - p0; du_flip += e1 - e0; dpair_flip += q1 - q0;
+            new_lower_p = on ? (1 + dot3(rf, nl)) / 2 : (R)0;
+            dpsi_flip += on ? p1 - p0 : (R)0; du_flip += on ? e1 - e0 : (R)0; dpair_flip += on ? q1 - q0 : (R)0;
           }
         }
+        R ratio;
         if constexpr (sizeof(R) == 8)
-          alpha = ((1 - new_upper_p) * (1 - new_lower_p)) / ((1 - upper_p) * (1 - lower_p));   // :328-329
+          ratio = ((1 - new_upper_p) * (1 - new_lower_p)) / ((1 - upper_p) * (1 - lower_p));   // :328-329
         else
-          alpha = ((1 - new_upper_p) * (1 - new_lower_p)) * __builtin_amdgcn_rcpf((1 - upper_p) * (1 - lower_p));
+          ratio = ((1 - new_upper_p) * (1 - new_lower_p)) * __builtin_amdgcn_rcpf((1 - upper_p) * (1 - lower_p));
+        alpha = flipped ? ratio : (R)1;
         // members' own terms: n_z -> -n_z; dielectric mu -> (-mu_x, -mu_y, mu_z), polar mu_z -> -mu_z
-        drz_flip = b * (-2 * snz);
-        if constexpr (CT == PSTAT_DIELECTRIC) { dp_flip.x = -2 * sm.x; dp_flip.y = -2 * sm.y; }
-        else { dp_flip.z = -2 * sm.z; du_flip += mhalfE0 * dp_flip.z; }
+        const R f2 = flipped ? (R)-2 : (R)0;
+        drz_flip = b * (f2 * snz);
+        if constexpr (CT == PSTAT_DIELECTRIC) { dp_flip.x = f2 * sm.x; dp_flip.y = f2 * sm.y; }
+        else { dp_flip.z = f2 * sm.z; du_flip += mhalfE0 * dp_flip.z; }
       }
       const uint32_t weps = g.next();   // the acceptance draw comes after the cluster's draws
 
