@@ -125,6 +125,21 @@ def test_julia_hosts_mirror_the_structs(ps):
         for f, t in ps._lib.Summary._fields_:
             want.append((f, jl_type[t] if t in jl_type else "NTuple{%d,Cdouble}" % (C.sizeof(t) // 8)))
         assert got == want, name
+        # the positional constructor call passes exactly one argument per field
+        i = src.index("  PstatParams(pargs[") + len("  PstatParams(")
+        depth, args = 1, 1
+        while depth > 0:
+            c = src[i]
+            if c in "([":
+                depth += 1
+            elif c in ")]":
+                depth -= 1
+            elif c == "," and depth == 1:
+                args += 1
+            elif c == "#":
+                i = src.index("\n", i)
+            i += 1
+        assert args == len(ps._lib.Params._fields_), (name, args)
         # every ccall names a symbol the library exports
         for sym in set(re.findall(r"ccall\(\(:(\w+), LIBPSTAT\)", src)):
             assert sym in ps._lib.SYMBOLS, (name, sym)
