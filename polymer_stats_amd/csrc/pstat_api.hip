@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -223,6 +224,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
 
   pstat_handle *h = new (std::nothrow) pstat_handle;
   if (!h) return fail(PSTAT_ERR_NOMEM, "host allocation failed");
+  try {   // std::vector growth may throw: nothing propagates through the C ABI
   h->base = cases[0];
   h->ncases = ncases;
   h->device = cases[0].device;
@@ -352,6 +354,10 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   }
 #undef CREATE_TRY
 #undef CREATE_HIP
+  } catch (const std::bad_alloc &) {
+    pstat_destroy(h);
+    return fail(PSTAT_ERR_NOMEM, "host allocation failed");
+  }
   *out = h;
   return PSTAT_OK;
 }
@@ -644,16 +650,17 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sum
   const size_t C = (size_t)h->S.C, n = (size_t)h->base.n;
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (angles) {
-    std::vector<unsigned char> tmp(2 * n * h->elem);
-    HIP_TRY(hipMemcpy2D(tmp.data(), h->elem, (char *)h->S.ang + (size_t)chain * h->elem, C * h->elem,
+    std::unique_ptr<unsigned char[]> tmp(new (std::nothrow) unsigned char[2 * n * h->elem]);
+    if (!tmp) return fail(PSTAT_ERR_NOMEM, "host allocation failed");
+    HIP_TRY(hipMemcpy2D(tmp.get(), h->elem, (char *)h->S.ang + (size_t)chain * h->elem, C * h->elem,
                         h->elem, 2 * n, hipMemcpyDeviceToHost));
     // storage formats: pstat_math.h (radians | turns | lattice index); the ABI speaks radians
     for (size_t i = 0; i < 2 * n; ++i) {
       const bool is_theta = i < n;
-      if (h->elem == 8) angles[i] = ((double *)tmp.data())[i];
-      else if (h->elem == 4) angles[i] = (double)((float *)tmp.data())[i] * 6.28318530717958647692;
+      if (h->elem == 8) angles[i] = ((double *)tmp.get())[i];
+      else if (h->elem == 4) angles[i] = (double)((float *)tmp.get())[i] * 6.28318530717958647692;
       else angles[i] = (is_theta ? 3.14159265358979323846 : 6.28318530717958647692) *
-                       ((double)((uint16_t *)tmp.data())[i] + 0.5) / 65536.0;
+                       ((double)((uint16_t *)tmp.get())[i] + 0.5) / 65536.0;
     }
   }
   if (sums) {
