@@ -39,14 +39,34 @@ struct Cfg {  // one configuration of the chain, M monomers per lane, and its ch
   R rx, ry, rz, px, py, pz, usum, psisum, c2sum, upair, U;
 };
 
+// Waves per SIMD asked of the register allocator.  Measured, 16 384 chains: f32 M = 1 at 4 instead of the 2 it
+// takes by itself +41 % at n = 64 (3: +25 %; 5 spills: -10 %), M = 4 at 2 instead of 1 +24 % at n = 200, M = 2
+// stays at 2 (3: -4 % at n = 100), M = 8 needs one wave's 512 registers; f64 M = 1, 2 at 2 instead of 1:
+// +38 % at n = 64, +23 % at n = 100 (a few spilled registers outside the pair loop).
+#ifndef PSTAT_WOCC_M1
+#define PSTAT_WOCC_M1 4
+#endif
+#ifndef PSTAT_WOCC_M2
+#define PSTAT_WOCC_M2 2
+#endif
+#ifndef PSTAT_WOCC_M4
+#define PSTAT_WOCC_M4 2
+#endif
 template <typename R, typename G, int CT, int M>
-__global__ __launch_bounds__(64) void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
+#ifndef PSTAT_WOCC_F64M1
+#define PSTAT_WOCC_F64M1 2
+#endif
+#ifndef PSTAT_WOCC_F64M2
+#define PSTAT_WOCC_F64M2 2
+#endif
+__global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? PSTAT_WOCC_F64M1 : (M == 2 ? PSTAT_WOCC_F64M2 : 1)) : (M == 1 ? PSTAT_WOCC_M1 : (M == 2 ? PSTAT_WOCC_M2 : (M == 4 ? PSTAT_WOCC_M4 : 1))))
+void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
                                                           int umb, int cutoff) {
   using AG = Ang<R>;
   using R4 = typename std::conditional<sizeof(R) == 4, float4, double4>::type;
   using R2 = typename Vec2<R>::type;
   __shared__ R4 ringA[128 * M];   // (x, y, z, mu_x) of monomer e mod 64M at entry e
-  __shared__ R2 ringB[128 * M];   // (mu_y, mu_z)
+  __shared__ R2 ringB[128 * M * (sizeof(R) == 4 ? 2 : 1)];   // (mu_y, mu_z); f32: 16-byte entries (pstat_wave.h)
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   const int64_t C = S.C;
@@ -151,9 +171,7 @@ __global__ __launch_bounds__(64) void cluster_wave_kernel(SweepArgs A, DevState 
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
   const R uref = umb ? (R)S.uref[c] : (R)0;
   double wnorm = umb ? S.wnorm[c] : 0.0;
-  double sums[NSUMS];
-#pragma unroll
-  for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
+  // the f64 running sums stay in HBM: lane 0 adds a block of steps to them every FLUSH steps
   const R inv_nm1 = n > 1 ? (R)(1.0 / (double)(n - 1)) : (R)0;
 
   derive(cur);
@@ -274,12 +292,15 @@ __global__ __launch_bounds__(64) void cluster_wave_kernel(SweepArgs A, DevState 
       for (int q = 0; q < 7; ++q) acc2[q] = fma_r(wgt * obs[q], obs[q], acc2[q]);
     }
 
-    sums[S_R1] += (double)acc1[0]; sums[S_R2] += (double)acc1[1]; sums[S_R3] += (double)acc1[2];
-    sums[S_P1] += (double)acc1[3]; sums[S_P2] += (double)acc1[4]; sums[S_P3] += (double)acc1[5];
-    sums[S_U] += (double)acc1[6]; sums[S_C2] += (double)acc1[7]; sums[S_PSI] += (double)acc1[8];
-    sums[S_R1SQ] += (double)acc2[0]; sums[S_R2SQ] += (double)acc2[1]; sums[S_R3SQ] += (double)acc2[2];
-    sums[S_P1SQ] += (double)acc2[3]; sums[S_P2SQ] += (double)acc2[4]; sums[S_P3SQ] += (double)acc2[5];
-    sums[S_USQ] += (double)acc2[6];
+    if (lane == 0) {
+      auto add = [&](const int q, const R v) { S.sums[q * C + c] += (double)v; };
+      add(S_R1, acc1[0]); add(S_R2, acc1[1]); add(S_R3, acc1[2]);
+      add(S_P1, acc1[3]); add(S_P2, acc1[4]); add(S_P3, acc1[5]);
+      add(S_U, acc1[6]); add(S_C2, acc1[7]); add(S_PSI, acc1[8]);
+      add(S_R1SQ, acc2[0]); add(S_R2SQ, acc2[1]); add(S_R3SQ, acc2[2]);
+      add(S_P1SQ, acc2[3]); add(S_P2SQ, acc2[4]); add(S_P3SQ, acc2[5]);
+      add(S_USQ, acc2[6]);
+    }
     wnorm += (double)accw;
     step += chunk;
     remaining -= chunk;
@@ -326,7 +347,6 @@ __global__ __launch_bounds__(64) void cluster_wave_kernel(SweepArgs A, DevState 
     S.obs[OBS_C2 * C + c] = cur.c2sum; S.obs[OBS_PSI * C + c] = cur.psisum;
     S.lag[c] = lag;
     if (umb) S.wnorm[c] = wnorm;
-    for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
   }
 }
 

@@ -35,7 +35,23 @@ namespace pstat {
 // M consecutive monomers per lane: lane l owns monomers l*M .. l*M + M-1 (n <= 64 M).
 // (f64, M = 1 sits at the 256-VGPR boundary: ask for two waves per SIMD so that it stays on the good side)
 template <typename R, typename G, int CT, int M>
-__global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void interacting_kernel(SweepArgs A, DevState S,
+// f32 waves per SIMD asked of the register allocator for M = 1, 2, 4 (measured, 16 384 chains: M = 1 at
+// 4 instead of the 3 it takes by itself +2 % at n = 64, +10 % at n = 23; M = 4 at 2 instead of 1 +16 % at
+// n = 200; M = 2 at 3 instead of 2 loses 4 % at n = 100)
+#ifndef PSTAT_IOCC_M1
+#define PSTAT_IOCC_M1 4
+#endif
+#ifndef PSTAT_IOCC_M2
+#define PSTAT_IOCC_M2 2
+#endif
+#ifndef PSTAT_IOCC_M4
+#define PSTAT_IOCC_M4 2
+#endif
+#ifndef PSTAT_IOCC_F64M2
+#define PSTAT_IOCC_F64M2 2
+#endif
+__global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? 2 : (M == 2 ? PSTAT_IOCC_F64M2 : 1))
+                                                : (M == 1 ? PSTAT_IOCC_M1 : (M == 2 ? PSTAT_IOCC_M2 : PSTAT_IOCC_M4))) void interacting_kernel(SweepArgs A, DevState S,
                                                          const CaseConst *__restrict__ cases,
                                                          int do_flips, int use_lag, int umb,
                                                          int reinit_mode /* 0 | 1 metropolis | 2 forced */) {
@@ -43,7 +59,7 @@ __global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void intera
   using R4 = typename std::conditional<sizeof(R) == 4, float4, double4>::type;
   using R2 = typename Vec2<R>::type;
   __shared__ R4 ringA[128 * M];   // (x, y, z, mu_x) of monomer e mod 64M at entry e
-  __shared__ R2 ringB[128 * M];   // (mu_y, mu_z)
+  __shared__ R2 ringB[128 * M * (sizeof(R) == 4 ? 2 : 1)];   // (mu_y, mu_z); f32: 16-byte entries (pstat_wave.h)
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   const int64_t C = S.C;
@@ -82,9 +98,8 @@ __global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void intera
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
   const R uref = umb ? (R)S.uref[c] : (R)0;
   double wnorm = umb ? S.wnorm[c] : 0.0;
-  double sums[NSUMS_BASE];
-#pragma unroll
-  for (int q = 0; q < NSUMS_BASE; ++q) sums[q] = S.sums[q * C + c];
+  // the f64 running sums stay in HBM: lane 0 adds a block of steps to them every FLUSH steps (28 VGPRs
+  // that the pair loop can use instead)
 
   // ---- derive my monomers and the chain totals (inc/eap_chain.jl:109-134)
   R st[M], nx[M], ny[M], nz[M], mx[M], my[M], mz[M], xx[M], xy[M], xz[M];
@@ -276,12 +291,15 @@ __global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void intera
       }
     }
 
-    sums[S_R1] += (double)acc1[0]; sums[S_R2] += (double)acc1[1]; sums[S_R3] += (double)acc1[2];
-    sums[S_P1] += (double)acc1[3]; sums[S_P2] += (double)acc1[4]; sums[S_P3] += (double)acc1[5];
-    sums[S_U] += (double)acc1[6];
-    sums[S_R1SQ] += (double)acc2[0]; sums[S_R2SQ] += (double)acc2[1]; sums[S_R3SQ] += (double)acc2[2];
-    sums[S_P1SQ] += (double)acc2[3]; sums[S_P2SQ] += (double)acc2[4]; sums[S_P3SQ] += (double)acc2[5];
-    sums[S_USQ] += (double)acc2[6];
+    if (lane == 0) {
+      auto add = [&](const int q, const R v) { S.sums[q * C + c] += (double)v; };
+      add(S_R1, acc1[0]); add(S_R2, acc1[1]); add(S_R3, acc1[2]);
+      add(S_P1, acc1[3]); add(S_P2, acc1[4]); add(S_P3, acc1[5]);
+      add(S_U, acc1[6]);
+      add(S_R1SQ, acc2[0]); add(S_R2SQ, acc2[1]); add(S_R3SQ, acc2[2]);
+      add(S_P1SQ, acc2[3]); add(S_P2SQ, acc2[4]); add(S_P3SQ, acc2[5]);
+      add(S_USQ, acc2[6]);
+    }
     wnorm += (double)accw;
     step += chunk;
     remaining -= chunk;
@@ -336,7 +354,6 @@ __global__ __launch_bounds__(64, (sizeof(R) == 8 && M == 1) ? 2 : 1) void intera
     S.obs[OBS_U * C + c] = U; S.obs[OBS_USUM * C + c] = usum;
     S.lag[c] = lag;
     if (umb) S.wnorm[c] = wnorm;
-    for (int q = 0; q < NSUMS_BASE; ++q) S.sums[q * C + c] = sums[q];
   }
 }
 

@@ -1,5 +1,5 @@
 // ubench.hip -- instruction-rate and trig-accuracy microbenchmarks that size the sweep kernel's
-// design choices on gfx950.  Build: hipcc -O3 --offload-arch=gfx950 tools/ubench.hip -o tools/ubench
+// design choices on gfx950.  Build: hipcc -O3 -fno-slp-vectorize --offload-arch=gfx950 tools/ubench.hip -o tools/ubench
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -8,10 +8,10 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-constexpr int ITERS = 4096;
+constexpr int ITERS = 32768;
 constexpr int ACC = 8;
 
-enum Op { PKFMA_IND, PKADD_IND, FMA32, MULLO, MULHI, SIN, EXP2, RCP, FMA64, ADD64, XORSHIFT, CVT, PKFMA, LDSB64, MAD64, ALIGNBIT, XOR32, ADDU32, XOSHIRO, MWC64X, DPP_WAVE_ROR, DPP_ROW_ROR, BPERMUTE, DPP_WAVE_ROR_IND };
+enum Op { FMA_3V, FMAC_3V, MUL_2V, PKFMA_3V, FMA_1V1S, PKFMA_IND, PKADD_IND, FMA32, MULLO, MULHI, SIN, EXP2, RCP, FMA64, ADD64, XORSHIFT, CVT, PKFMA, LDSB64, MAD64, ALIGNBIT, XOR32, ADDU32, XOSHIRO, MWC64X, DPP_WAVE_ROR, DPP_ROW_ROR, BPERMUTE, DPP_WAVE_ROR_IND };
 
 template <int OP>
 __global__ __launch_bounds__(64) void rate_kernel(float *out, int nrows) {
@@ -22,9 +22,22 @@ __global__ __launch_bounds__(64) void rate_kernel(float *out, int nrows) {
   for (int i = 0; i < ACC; ++i) pk[i] = (v2q){0.001f * (threadIdx.x + i + 1), 0.002f * (threadIdx.x + i + 1)};
   for (int i = 0; i < ACC; ++i) { a[i] = 0.001f * (threadIdx.x + i + 1); u[i] = threadIdx.x * 2654435761u + i; d[i] = a[i]; }
   if (OP == LDSB64) for (int r = 0; r < nrows; ++r) lds[r * 64 + threadIdx.x] = make_float2(r, threadIdx.x);
+  // operands that live in VGPRs (per-lane values the compiler cannot fold)
+  float bq[ACC], cq[ACC]; v2q pb[ACC], pc[ACC];
+  for (int i = 0; i < ACC; ++i) {
+    bq[i] = 1.0f + 1e-6f * (threadIdx.x + i); cq[i] = 1e-3f * (threadIdx.x + 2 * i + 1);
+    pb[i] = (v2q){bq[i], bq[i] + 1e-7f}; pc[i] = (v2q){cq[i], cq[i] * 0.5f};
+  }
+  const float sconst = 1.0f + 1e-6f * (float)nrows;   // wave-uniform: an SGPR operand
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int i = 0; i < ACC; ++i) {
+      // how many DISTINCT VGPR sources an instruction reads
+      if (OP == FMA_3V) a[i] = __builtin_fmaf(a[i], bq[i], cq[i]);            // v_fma_f32 d, v, v, v
+      if (OP == FMAC_3V) a[i] = __builtin_fmaf(bq[i], cq[(i + 1) % ACC], a[i]);   // v_fmac_f32 acc, v, v
+      if (OP == MUL_2V) a[i] = a[i] * bq[i];                                   // v_mul_f32 d, v, v
+      if (OP == FMA_1V1S) a[i] = __builtin_fmaf(a[i], sconst, 0.5f);           // v_fma_f32 d, v, s, const
+      if (OP == PKFMA_3V) pk[i] = __builtin_elementwise_fma(pk[i], pb[i], pc[i]);
       if (OP == FMA32) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
       // packed ops on ACC independent register pairs: the issue cost of v_pk_fma_f32 / v_pk_add_f32 themselves
       if (OP == PKFMA_IND) pk[i] = __builtin_elementwise_fma(pk[i], (v2q){1.0001f, 1.0002f}, (v2q){0.5f, 0.25f});
@@ -59,7 +72,7 @@ __global__ __launch_bounds__(64) void rate_kernel(float *out, int nrows) {
       }
     }
   }
-  float s = 0; for (int i = 0; i < ACC; ++i) s += a[i] + (float)u[i] + (float)d[i] + pk[i].x + pk[i].y;
+  float s = 0; for (int i = 0; i < ACC; ++i) s += a[i] + (float)u[i] + (float)d[i] + pk[i].x + pk[i].y + bq[i] + cq[i] + pb[i].y + pc[i].y;
   if (s == 123.456f) out[0] = s;
 }
 
@@ -148,16 +161,22 @@ __global__ void trig_err_kernel(int n, double *maxerr) {
   }
 }
 
-int main() {
+int main(int argc, char **argv) {
+  const bool only_ops = argc > 1 && argv[1][0] == 'o';   // "ops": just the operand-source rates
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d kHz  LDS/CU=%zu\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate, prop.maxSharedMemoryPerMultiProcessor);
-  for (int w : {4, 8, 16}) {
+  if (!only_ops) for (int w : {4, 8, 16}) {
     run<FMA32>("fma_f32", w); run<MULLO>("mul_lo_u32", w); run<MULHI>("mul_hi_u32", w);
     run<SIN>("v_sin_f32", w); run<EXP2>("v_exp_f32", w); run<RCP>("v_rcp_f32", w);
     run<FMA64>("fma_f64", w); run<ADD64>("add_f64", w); run<XORSHIFT>("xor/shl/rot", w);
     run<CVT>("cvt+add", w); run<PKFMA>("pk_fma_f32 (pair assembled per op)", w);
     run<PKFMA_IND>("pk_fma_f32 independent", w); run<PKADD_IND>("pk_add_f32 independent", w);
   }
+  for (int w : {4, 8, 12, 16}) {
+    run<FMA_1V1S>("fma d,v,s,c", w); run<MUL_2V>("mul d,v,v", w); run<FMA_3V>("fma d,v,v,v", w);
+    run<FMAC_3V>("fmac acc,v,v", w); run<PKFMA_3V>("pk_fma d,v,v,v", w);
+  }
+  if (only_ops) return 0;
   for (int w : {4, 8}) { run<MAD64>("mad_u64_u32", w); run<ALIGNBIT>("alignbit", w); run<XOR32>("xor_b32", w); run<ADDU32>("add_u32", w); }
   for (int w : {4, 12, 16}) { run<DPP_WAVE_ROR>("dpp wave_ror", w); run<DPP_ROW_ROR>("dpp row_ror", w); run<BPERMUTE>("ds_bpermute", w); run<DPP_WAVE_ROR_IND>("wave_ror+add", w); }
   for (int w : {4, 8}) { run_gen<0>("xoshiro128++", w); run_gen<1>("mwc64x", w); }
