@@ -220,10 +220,13 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   Cell aA = slot(dA.cell), aB = aA;
   R phistep3 = 3 * phistep, thstep3 = 3 * thstep;
   (void)phistep3; (void)thstep3;
+  P stepv = {thstep, phistep}, step3v = {thstep3, phistep3};   // f32: the (theta, phi) proposal as one 2-vector
+  (void)stepv; (void)step3v;
   int left = (int)remaining;        // steps still to run in this segment (<= 2^30)
   // running observables: (rx, ry) and (px, py) as pairs, the z components and U as scalars
   P Orxy = {O[0], O[1]}, Opxy = {O[3], O[4]};
-  R Orz = O[2], Opz = O[5], OU = O[6];
+  P Oz = {O[2], O[5]};              // {r_z, p_z}
+  R OU = O[6];
   const P bb = {b, b};
   (void)bb;
 
@@ -258,8 +261,9 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     // vectoriser re-pair the accumulators of the hot loop, which costs it ~10 moves per step)
     auto opaque = [](R v) __attribute__((always_inline)) -> R { asm volatile("" : "+v"(v)); return v; };
     const double bd = (double)b;
-    Orxy.x = opaque((R)(bd * tx)); Orxy.y = opaque((R)(bd * ty)); Orz = opaque((R)(bd * tz));
-    Opxy.x = opaque((R)qx); Opxy.y = opaque((R)qy); Opz = opaque((R)qz);
+    // f32 carries r in units of b (the hot loop then needs no m*b): r_x, r_y, r_z here are sums of n
+    Orxy.x = opaque((R)tx); Orxy.y = opaque((R)ty); Oz.x = opaque((R)tz);
+    Opxy.x = opaque((R)qx); Opxy.y = opaque((R)qy); Oz.y = opaque((R)qz);
     usum = opaque((R)tu);
     OU = opaque((R)(tu + tp - ((double)Fx * bd * tx + (double)Fz * bd * tz)));
   };
@@ -270,7 +274,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     int chunk = left < FLUSH ? left : FLUSH;
     if (A.adaptive && to_adj < chunk) chunk = (int)to_adj;
     P a1rxy = {0, 0}, a1pxy = {0, 0}, a2rxy = {0, 0}, a2pxy = {0, 0};
-    R a1rz = 0, a1pz = 0, a1U = 0, a2rz = 0, a2pz = 0, a2U = 0;
+    P a1z = {0, 0}, a2z = {0, 0};
+    R a1U = 0, a2U = 0;
     R accw = 0;
 
     // one Monte-Carlo step on (d, a0); fetches the next step's draws and LDS row into (dn, an)
@@ -279,6 +284,9 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       if (more) {
         dn = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes);
         an = slot(dn.cell);
+        // keep the next row's read up here, a whole step ahead of its use: left alone, the scheduler sinks it
+        // to ~12 instructions before the forwarding select, and a lone wave then waits for LDS (+1 % measured)
+        __builtin_amdgcn_sched_barrier(0);
       }
       // ---- proposal, mcmc_eap_chain.jl:277-280, and trial angles, inc/eap_chain.jl:232-236
       R eps;                        // u in [0,1) (f64) or 1 + u (f32: the -1 is folded into the test)
@@ -315,10 +323,12 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
           th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
         } else {
           // angle + step * (f - 3) with f in [2,4): the -3*step rides on the base angle
-          ph1 = AG::wrap(fma_r(phistep, bits24(d.wphi), ph0 - phistep3));
           R base = th0;
           if constexpr (RARE) base = th0 + flip;
-          th1 = fmin(AG::theta_max, fmax((R)0, fma_r(thstep, bits24(d.wth), base - thstep3)));
+          const P basev = {base, ph0}, fv = {bits24(d.wth), bits24(d.wphi)};
+          const P raw = pfma(stepv, fv, basev - step3v);
+          th1 = fmin(AG::theta_max, fmax((R)0, raw.x));
+          ph1 = AG::wrap(raw.y);
         }
       }
       R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
@@ -344,11 +354,15 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         mz0 = a_or_mu * ct0; mz1 = a_or_mu * ct1;
       }
       const P dNxy = Nxy1 - Nxy0, dMxy = Mxy1 - Mxy0;
-      const R dnz = ct1 - ct0, dmz = mz1 - mz0;
+      // the z components travel as {n_z, mu_z} pairs: D = {dn_z, dmu_z}
+      const P Z0 = {ct0, mz0}, Z1 = {ct1, mz1};
+      const P D = Z1 - Z0;
+      const R dnz = D.x, dmz = D.y;
+      (void)dnz;
 
       // ---- energy difference, inc/energy.jl:7-9,20-23; inc/eap_chain.jl:53
-      const R du = mhalfE0 * dmz;
-      const R drz = b * dnz;
+      const P dd = D * P{b, mhalfE0};
+      const R drz = dd.x, du = dd.y;
       R dpair = 0;
       if constexpr (EN == PSTAT_ISING) {
         R e0 = 0, e1 = 0;
@@ -404,15 +418,12 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       const P mm = {m, m};
       if constexpr (sizeof(R) == 8) {  // the oracle's update order: r += b*dn, p += dm, U += dU
         Orxy = pfma(mm, bb * dNxy, Orxy);
-        Orz = m * drz + Orz;
-      } else {
-        const R mb = m * b;
-        const P mbs = {mb, mb};
-        Orxy = pfma(mbs, dNxy, Orxy);
-        Orz = fma_r(mb, dnz, Orz);
+        Oz = pfma(mm, P{drz, dmz}, Oz);
+      } else {                         // f32: r is carried in units of b (see unit_r)
+        Orxy = pfma(mm, dNxy, Orxy);
+        Oz = pfma(mm, D, Oz);
       }
       Opxy = pfma(mm, dMxy, Opxy);
-      Opz = fma_r(m, dmz, Opz);
       if constexpr (EN == PSTAT_ISING) OU = ok ? OU + dU : OU;  // dU may be inf/NaN (1/r^3): 0*NaN would poison U
       else                             OU = fma_r(m, dU, OU);
       if constexpr (RARE) {
@@ -433,13 +444,13 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         accw += wgt;
         a1rxy = pfma(ww, Orxy, a1rxy); a1pxy = pfma(ww, Opxy, a1pxy);
         a2rxy = pfma(ww * Orxy, Orxy, a2rxy); a2pxy = pfma(ww * Opxy, Opxy, a2pxy);
-        a1rz = fma_r(wgt, Orz, a1rz); a1pz = fma_r(wgt, Opz, a1pz); a1U = fma_r(wgt, OU, a1U);
-        a2rz = fma_r(wgt * Orz, Orz, a2rz); a2pz = fma_r(wgt * Opz, Opz, a2pz); a2U = fma_r(wgt * OU, OU, a2U);
+        a1z = pfma(ww, Oz, a1z); a1U = fma_r(wgt, OU, a1U);
+        a2z = pfma(ww * Oz, Oz, a2z); a2U = fma_r(wgt * OU, OU, a2U);
       } else {
         a1rxy += Orxy; a1pxy += Opxy;
         a2rxy = pfma(Orxy, Orxy, a2rxy); a2pxy = pfma(Opxy, Opxy, a2pxy);
-        a1rz += Orz; a1pz += Opz; a1U += OU;
-        a2rz = fma_r(Orz, Orz, a2rz); a2pz = fma_r(Opz, Opz, a2pz); a2U = fma_r(OU, OU, a2U);
+        a1z += Oz; a1U += OU;
+        a2z = pfma(Oz, Oz, a2z); a2U = fma_r(OU, OU, a2U);
       }
     };
     // ping-pong between two (draw, row) register sets: no copies in the steady state
@@ -467,8 +478,12 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       dA = dB; aA = aB;
     }
 
-    R acc1[7] = {a1rxy.x, a1rxy.y, a1rz, a1pxy.x, a1pxy.y, a1pz, a1U};
-    R acc2[7] = {a2rxy.x, a2rxy.y, a2rz, a2pxy.x, a2pxy.y, a2pz, a2U};
+    R acc1[7] = {a1rxy.x, a1rxy.y, a1z.x, a1pxy.x, a1pxy.y, a1z.y, a1U};
+    R acc2[7] = {a2rxy.x, a2rxy.y, a2z.x, a2pxy.x, a2pxy.y, a2z.y, a2U};
+    if constexpr (sizeof(R) == 4) {   // r was carried in units of b
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { acc1[q] *= b; acc2[q] *= b * b; }
+    }
     sums[S_R1] += (double)acc1[0]; sums[S_R2] += (double)acc1[1]; sums[S_R3] += (double)acc1[2];
     sums[S_P1] += (double)acc1[3]; sums[S_P2] += (double)acc1[4]; sums[S_P3] += (double)acc1[5];
     sums[S_U] += (double)acc1[6];
@@ -498,6 +513,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         }
         phistep = (R)(phistep_d / ph_unit); thstep = (R)(thstep_d / th_unit);
         phistep3 = 3 * phistep; thstep3 = 3 * thstep;
+        stepv = P{thstep, phistep}; step3v = P{thstep3, phistep3};
       }
     }
   }
@@ -522,8 +538,9 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
   S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
   S.nacc_total[c] += nacc_seg;
-  S.obs[OBS_R1 * C + c] = Orxy.x; S.obs[OBS_R2 * C + c] = Orxy.y; S.obs[OBS_R3 * C + c] = Orz;
-  S.obs[OBS_P1 * C + c] = Opxy.x; S.obs[OBS_P2 * C + c] = Opxy.y; S.obs[OBS_P3 * C + c] = Opz;
+  const R unit_r = sizeof(R) == 4 ? b : (R)1;   // f32 carries r in units of b
+  S.obs[OBS_R1 * C + c] = unit_r * Orxy.x; S.obs[OBS_R2 * C + c] = unit_r * Orxy.y; S.obs[OBS_R3 * C + c] = unit_r * Oz.x;
+  S.obs[OBS_P1 * C + c] = Opxy.x; S.obs[OBS_P2 * C + c] = Opxy.y; S.obs[OBS_P3 * C + c] = Oz.y;
   S.obs[OBS_U * C + c] = OU;
   if constexpr (RARE) S.obs[OBS_USUM * C + c] = usum;   // only the umbrella weights ever read it
   if constexpr (RARE) {
