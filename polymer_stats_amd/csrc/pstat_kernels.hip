@@ -28,6 +28,9 @@
 #include "../../include/pstat.h"
 #include "pstat_math.h"
 
+#ifndef PSTAT_UNROLL_ISING
+#define PSTAT_UNROLL_ISING 16  // the Ising step is ~3x as long
+#endif
 #ifndef PSTAT_UNROLL
 #define PSTAT_UNROLL 16  // steps per basic block of the sweep loop (even; measured: 8 -> 16 +1.2 %, 32 -4 %)
 #endif
@@ -160,8 +163,9 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   const R k2e = (R)(cc.K2 * cc.E0);
   const R mhalfE0 = (R)(-0.5 * cc.E0);
   const R hb = (R)(-cc.b / 2);
+  const R ising_scale = (R)(0.0795774715459476679 / fabs(cc.b * cc.b * cc.b / 8));   // f32 Ising: see the step
   const R nbeta_log2e = (R)(-1.4426950408889634 / cc.kT);  // exp(-dU/kT) = exp2(dU * this)
-  (void)Fx; (void)kT; (void)hb; (void)nbeta_log2e;
+  (void)Fx; (void)kT; (void)hb; (void)nbeta_log2e; (void)ising_scale;
 
   // ---- fill
   if constexpr (Q) {
@@ -336,36 +340,27 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       AG::sc(th1, &st1, &ct1);
       AG::sc(ph0, &sp0, &cp0);
       AG::sc(ph1, &sp1, &cp1);
-      // (x, y) components travel as one 2-vector: {n_x, n_y} = sin(theta) * {cos(phi), sin(phi)}
-      // (inc/eap_chain.jl:40), so the old->new differences come out packed with no shuffles
-      const P cs0 = {cp0, sp0}, cs1 = {cp1, sp1};
-      const P s0s = {st0, st0}, s1s = {st1, st1};
-      const P Nxy0 = cs0 * s0s, Nxy1 = cs1 * s1s;
-      P Mxy0, Mxy1;
-      R mz0, mz1;                                         // dipole, inc/dipole_response.jl:7-29
-      if constexpr (CT == PSTAT_DIELECTRIC) {
-        const R q0 = a_or_mu * ct0, q1 = a_or_mu * ct1;  // (K1-K2) E0 cos(theta)
-        const P q0s = {q0, q0}, q1s = {q1, q1};
-        Mxy0 = q0s * Nxy0; Mxy1 = q1s * Nxy1;
-        mz0 = q0 * ct0 + k2e; mz1 = q1 * ct1 + k2e;
-      } else {
-        const P mus = {a_or_mu, a_or_mu};
-        Mxy0 = mus * Nxy0; Mxy1 = mus * Nxy1;
-        mz0 = a_or_mu * ct0; mz1 = a_or_mu * ct1;
-      }
-      const P dNxy = Nxy1 - Nxy0, dMxy = Mxy1 - Mxy0;
-      // the z components travel as {n_z, mu_z} pairs: D = {dn_z, dmu_z}
-      const P Z0 = {ct0, mz0}, Z1 = {ct1, mz1};
-      const P D = Z1 - Z0;
-      const R dnz = D.x, dmz = D.y;
-      (void)dnz;
-
-      // ---- energy difference, inc/energy.jl:7-9,20-23; inc/eap_chain.jl:53
-      const P dd = D * P{b, mhalfE0};
-      const R drz = dd.x, du = dd.y;
+      P dNxy, dMxy, D;   // old -> new differences of {n_x, n_y}, {mu_x, mu_y}, {n_z, mu_z}
       R dpair = 0;
-      if constexpr (EN == PSTAT_ISING) {
-        R e0 = 0, e1 = 0;
+      if constexpr (EN == PSTAT_ISING && sizeof(R) == 4) {
+        // f32 Ising: every quantity of the touched monomer travels as an {old, new} pair, so that the four
+        // neighbour terms (two neighbours x old/new) are two packed evaluations -- a lone wave pays per
+        // instruction, and a packed one costs little more than a scalar one
+        const P S01 = {st0, st1}, X01 = P{cp0, cp1} * S01, Y01 = P{sp0, sp1} * S01, C01 = {ct0, ct1};
+        P MX01, MY01, MZ01;                               // dipole, inc/dipole_response.jl:7-29
+        if constexpr (CT == PSTAT_DIELECTRIC) {
+          const P q01 = C01 * P{a_or_mu, a_or_mu};        // (K1-K2) E0 cos(theta)
+          MX01 = q01 * X01; MY01 = q01 * Y01;
+          MZ01 = pfma(q01, C01, P{k2e, k2e});
+        } else {
+          const P mus = {a_or_mu, a_or_mu};
+          MX01 = mus * X01; MY01 = mus * Y01; MZ01 = mus * C01;
+        }
+        dNxy = P{X01.y - X01.x, Y01.y - Y01.x};
+        dMxy = P{MX01.y - MX01.x, MY01.y - MY01.x};
+        D = P{C01.y - C01.x, MZ01.y - MZ01.x};
+        P e01 = {0, 0};
+        const P m3 = {-3.0f, -3.0f};
 #pragma unroll
         for (int side = -1; side <= 1; side += 2) {
           const int j = (int)d.idx + side;
@@ -379,14 +374,76 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
             AG::sc(phj, &spj, &cpj);
             const R njx = cpj * sj, njy = spj * sj, njz = cj;
             dipole<R, CT>(a_or_mu, k2e, njx, njy, njz, mjx, mjy, mjz);
-            e0 += pair_term_fast(hb * (Nxy0.x + njx), hb * (Nxy0.y + njy), hb * (ct0 + njz),
-                                 Mxy0.x, Mxy0.y, mz0, mjx, mjy, mjz);
-            e1 += pair_term_fast(hb * (Nxy1.x + njx), hb * (Nxy1.y + njy), hb * (ct1 + njz),
-                                 Mxy1.x, Mxy1.y, mz1, mjx, mjy, mjz);
+            // bond vector r = -b/2 (n_i + n_j), inc/eap_chain.jl:215-228; the term of :200-207.  Only r's
+            // direction (twice: the sign cancels) and |r|^3 enter, so the sum runs on s = n_i + n_j and the
+            // factor 1/|b/2|^3 is applied once at the end
+            const P rx = X01 + P{njx, njx}, ry = Y01 + P{njy, njy}, rz = C01 + P{njz, njz};
+            const P jx = {mjx, mjx}, jy = {mjy, mjy}, jz = {mjz, mjz};
+            const P r2 = pfma(rz, rz, pfma(ry, ry, rx * rx));
+            const P ir = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+            const P ir2 = ir * ir;
+            const P mimj = pfma(MZ01, jz, pfma(MY01, jy, MX01 * jx));
+            const P mir = pfma(MZ01, rz, pfma(MY01, ry, MX01 * rx));
+            const P mjr = pfma(jz, rz, pfma(jy, ry, jx * rx));
+            const P num = pfma(m3 * ir2, mir * mjr, mimj);
+            e01 = pfma(num, ir2 * ir, e01);
           }
         }
-        dpair = e1 - e0;
+        dpair = (e01.y - e01.x) * ising_scale;              // 1/(4 pi |b/2|^3)
+      } else {
+        // (x, y) components travel as one 2-vector: {n_x, n_y} = sin(theta) * {cos(phi), sin(phi)}
+        // (inc/eap_chain.jl:40), so the old->new differences come out packed with no shuffles
+        const P cs0 = {cp0, sp0}, cs1 = {cp1, sp1};
+        const P s0s = {st0, st0}, s1s = {st1, st1};
+        const P Nxy0 = cs0 * s0s, Nxy1 = cs1 * s1s;
+        P Mxy0, Mxy1;
+        R mz0, mz1;                                         // dipole, inc/dipole_response.jl:7-29
+        if constexpr (CT == PSTAT_DIELECTRIC) {
+          const R q0 = a_or_mu * ct0, q1 = a_or_mu * ct1;  // (K1-K2) E0 cos(theta)
+          const P q0s = {q0, q0}, q1s = {q1, q1};
+          Mxy0 = q0s * Nxy0; Mxy1 = q1s * Nxy1;
+          mz0 = q0 * ct0 + k2e; mz1 = q1 * ct1 + k2e;
+        } else {
+          const P mus = {a_or_mu, a_or_mu};
+          Mxy0 = mus * Nxy0; Mxy1 = mus * Nxy1;
+          mz0 = a_or_mu * ct0; mz1 = a_or_mu * ct1;
+        }
+        dNxy = Nxy1 - Nxy0; dMxy = Mxy1 - Mxy0;
+        // the z components travel as {n_z, mu_z} pairs: D = {dn_z, dmu_z}
+        const P Z0 = {ct0, mz0}, Z1 = {ct1, mz1};
+        D = Z1 - Z0;
+
+        // ---- energy difference, inc/energy.jl:7-9,20-23; inc/eap_chain.jl:53
+        if constexpr (EN == PSTAT_ISING) {
+          R e0 = 0, e1 = 0;
+  #pragma unroll
+          for (int side = -1; side <= 1; side += 2) {
+            const int j = (int)d.idx + side;
+            if (j >= 0 && j < n) {
+              const Cell aj = ang[j * lanes + lane];
+              R thj, phj;
+              if constexpr (Q) { thj = q16_theta_turns(aj & 0xFFFFu); phj = q16_phi_turns(aj >> 16); }
+              else { thj = aj.x; phj = aj.y; }
+              R sj, cj, spj, cpj, mjx, mjy, mjz;
+              AG::sc(thj, &sj, &cj);
+              AG::sc(phj, &spj, &cpj);
+              const R njx = cpj * sj, njy = spj * sj, njz = cj;
+              dipole<R, CT>(a_or_mu, k2e, njx, njy, njz, mjx, mjy, mjz);
+              e0 += pair_term_fast(hb * (Nxy0.x + njx), hb * (Nxy0.y + njy), hb * (ct0 + njz),
+                                   Mxy0.x, Mxy0.y, mz0, mjx, mjy, mjz);
+              e1 += pair_term_fast(hb * (Nxy1.x + njx), hb * (Nxy1.y + njy), hb * (ct1 + njz),
+                                   Mxy1.x, Mxy1.y, mz1, mjx, mjy, mjz);
+            }
+          }
+          dpair = e1 - e0;
+        }
       }
+      const R dmz = D.y;
+      (void)dmz;
+
+      // ---- energy difference, inc/energy.jl:7-9,20-23; inc/eap_chain.jl:53
+      const P dd = D * P{b, mhalfE0};
+      const R drz = dd.x, du = dd.y;
       R dUi = du;   // (x + 0 is not folded under IEEE rules: keep the zero terms out of the arithmetic)
       if constexpr (EN == PSTAT_ISING) dUi = du + dpair;
       R dU;
@@ -461,7 +518,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     int k = 0;
     // (f64: two steps per block -- its step is ~550 instructions, eight of them overflow the 64 KiB
     // instruction cache)
-    constexpr int UNROLL = sizeof(R) == 8 ? 2 : PSTAT_UNROLL;
+    constexpr int UNROLL = sizeof(R) == 8 ? 2 : (EN == PSTAT_ISING ? PSTAT_UNROLL_ISING : PSTAT_UNROLL);
     for (; k + (UNROLL - 1) < chunk; k += UNROLL) {
 #pragma unroll
       for (int u = 0; u < UNROLL; u += 2) {
