@@ -165,7 +165,7 @@ __device__ __forceinline__ R ring_pair_sum(R4 *ringA, R2 *ringB_, const int lane
 }
 
 // f32 form of ring_pair_sum for M >= 2: TWO partner monomers per instruction.  A v_pk_*_f32 occupies the
-// SIMD twice as long as its scalar form (tools/ubench: 4.5 vs 2.1 cycles), so this buys no arithmetic
+// SIMD about twice as long as its scalar form (tools/ubench: 5.2 vs 2.4-3.4 cycles), so this buys little arithmetic
 // throughput; what it buys is half the instruction stream and half the dependent accumulation chain per
 // term, which is what limits these kernels at 1-2 waves per SIMD.  For the halves of a packed register to be two
 // DIFFERENT partners without any shuffle, the ring stores the entries in PAIRS -- three float4 per two
