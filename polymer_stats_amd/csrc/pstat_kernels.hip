@@ -217,7 +217,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // software pipeline: the draws and the LDS row of the NEXT step are fetched while the current
   // step computes; if both steps hit the same monomer and the current one is accepted, the
   // prefetched row is replaced by the freshly accepted angles.
-  using P = typename V2<R>::type;   // {old, new}
+  using P = typename V2<R>::type;   // a 2-vector: (x, y), {n_z, mu_z}, (theta, phi) or {old, new}
   const uint32_t row_bytes = (uint32_t)lanes * (uint32_t)sizeof(Cell), lane_bytes = (uint32_t)lane * (uint32_t)sizeof(Cell);
   auto slot = [&](uint32_t off) __attribute__((always_inline)) -> Cell & { return *reinterpret_cast<Cell *>(smem + off); };
   Draw dA = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes), dB = dA;
@@ -227,7 +227,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   P stepv = {thstep, phistep}, step3v = {thstep3, phistep3};   // f32: the (theta, phi) proposal as one 2-vector
   (void)stepv; (void)step3v;
   int left = (int)remaining;        // steps still to run in this segment (<= 2^30)
-  // running observables: (rx, ry) and (px, py) as pairs, the z components and U as scalars
+  // running observables: (rx, ry), (px, py) and {rz, pz} as pairs, U as a scalar; f32 carries r in units of b
   P Orxy = {O[0], O[1]}, Opxy = {O[3], O[4]};
   P Oz = {O[2], O[5]};              // {r_z, p_z}
   R OU = O[6];
