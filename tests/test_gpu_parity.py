@@ -250,8 +250,9 @@ def test_f32_statistical_parity_config2(ps, oracle, golden, rng, prec):
                                 # the f32 Ising step sums its neighbour terms on n_i + n_j and scales by 1/|b/2|^3 once;
                                 # r is carried in units of b: a bond length != 1, Fx != 0 and both chain types
                                 dict(n=40, E0=1.0, K1=0.6, K2=0.2, Fz=0.3, Fx=0.2, b=1.3, kT=1.5, energy_type=2),
-                                dict(n=40, E0=0.5, mu=0.8, Fz=0.4, b=0.7, kT=2.0, energy_type=2, chain_type=1)],
-                         ids=["noninteracting", "ising-dielectric-b1.3", "ising-polar-b0.7"])
+                                dict(n=40, E0=0.5, mu=0.8, Fz=0.4, b=0.7, kT=2.0, energy_type=2, chain_type=1),
+                                dict(n=33, E0=1.2, mu=0.6, Fz=0.3, Fx=0.5, b=0.7, kT=0.8, chain_type=1, do_flips=1)],
+                         ids=["noninteracting", "ising-dielectric-b1.3", "ising-polar-b0.7", "polar-fx-flips-b0.7"])
 def test_f32_vs_f64_same_seeds(ps, kw):
     """Same seeds => same proposals, so the two precisions differ by arithmetic only."""
     nsteps, nch = 20000, 1024
