@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PSTAT_ABI_VERSION 4
+#define PSTAT_ABI_VERSION 5
 
 typedef enum pstat_status {
   PSTAT_OK = 0,
@@ -61,6 +61,7 @@ enum { PSTAT_F32 = 0, PSTAT_F64 = 1, PSTAT_Q16 = 2 };
  *   PSTAT_RNG_MWC64X        multiply-with-carry MWC64X, streams split by 2^40-output skip-ahead (default)
  *   PSTAT_RNG_XOSHIRO128PP  xoshiro128++ seeded per chain through Philox4x32-10 */
 enum { PSTAT_RNG_MWC64X = 0, PSTAT_RNG_XOSHIRO128PP = 1 };
+#define PSTAT_MWC64X_MAX_CHAINS (1ull << 22)   /* global chain ids with pairwise disjoint MWC64X streams */
 /* which main's step is run:
  *   PSTAT_MOVES_SINGLE   mcmc_eap_chain.jl:276-291 -- one single-monomer trial move per step (default)
  *   PSTAT_MOVES_CLUSTER  mcmc_clustering_eap_chain.jl:268-279 -- the same move followed, on the trial
@@ -80,7 +81,10 @@ typedef struct pstat_params {
   int64_t n;             /* --num-monomers                                                    */
   int64_t num_chains;    /* chains per case on this handle (ours)                             */
   uint64_t seed;         /* ours: the reference never seeds its RNG                           */
-  uint64_t chain_id0;    /* global id of this handle's first chain: shards over GPUs          */
+  uint64_t chain_id0;    /* global id of this handle's first chain: shards over GPUs.  With
+                          * PSTAT_RNG_MWC64X chain_id0 + num_chains must stay <= 2^22 (PSTAT_MWC64X_MAX_CHAINS):
+                          * chain k starts k * 2^40 outputs down ONE sequence of period ~2^63, so ids beyond
+                          * 2^23 would wrap onto earlier streams (the bound keeps a factor 2 in hand); xoshiro128++ has no such bound */
   int32_t chain_type;    /* PSTAT_DIELECTRIC | PSTAT_POLAR                                    */
   int32_t energy_type;   /* PSTAT_NONINTERACTING | PSTAT_INTERACTING | PSTAT_ISING | PSTAT_CUTOFF */
   int32_t do_flips;      /* --do-flips                                                        */
@@ -113,9 +117,12 @@ enum {
  *              acceptance ratio, sum_i cos^2(theta_i), the mean bond angle (the last two are recorded
  *              by the clustering main only, mcmc_clustering_eap_chain.jl:243-244)
  *   [20..38]   sum over chains of the squares of those per-chain means
+ *   [39]       proposals rejected because their trial energy was not finite (see pstat_summary.nan_rejects)
+ *   [40]       chains whose current configuration has collapsed (see pstat_summary.chains_collapsed)
  * Every entry is additive across handles/GPUs, so one all-reduce(SUM) merges ensembles. */
 #define PSTAT_NQ 19
-#define PSTAT_NRED (1 + 2 * PSTAT_NQ)
+#define PSTAT_NX 2
+#define PSTAT_NRED (1 + 2 * PSTAT_NQ + PSTAT_NX)
 
 /* The ten stdout quantities of mcmc_eap_chain.jl:386-395 plus bookkeeping. */
 typedef struct pstat_summary {
@@ -128,6 +135,15 @@ typedef struct pstat_summary {
   double attempted_updates;    /* num_chains * steps_per_chain                                  */
   double extra_avg[2];         /* <sum cos^2 theta>, <psi> (clustering main: "<cos2(theta)>", "<psi>") */
   double extra_stderr[2];
+  /* Failure surfacing.  The reference rejects a proposal whose energy is NaN silently
+   * (inc/acceptance.jl:29-39: every comparison with NaN is false) and has no excluded volume, so with the
+   * pair energies (inc/eap_chain.jl:200-207,215-228: 1/r^3) a chain can fall into r -> 0 and stay there.
+   *   nan_rejects       proposals, over all chains and recorded steps, whose trial energy was NaN or +-Inf
+   *                     (identically 0 for the non-interacting energy, whose dU is always finite);
+   *   chains_collapsed  chains whose CURRENT energy has |U| > 1e6 * n * kT -- no bounded-field configuration
+   *                     of separated monomers gets there; only a 1/r^3 singularity does. */
+  int64_t nan_rejects;
+  int64_t chains_collapsed;
 } pstat_summary;
 
 typedef struct pstat_handle pstat_handle;
@@ -197,7 +213,11 @@ int pstat_rolling(pstat_handle *h, int32_t icase, double avg_out[PSTAT_NOBS],
  * (`chain` counts over all cases: case = chain / num_chains).  Synchronises. */
 int pstat_microstate(pstat_handle *h, int64_t chain, double out[7]);
 
-/* The quantities printed at mcmc_eap_chain.jl:365,386-395.  Synchronises. */
+/* The quantities printed at mcmc_eap_chain.jl:365,386-395.  Synchronises.  Like every accessor that
+ * synchronises (pstat_sync, pstat_reduce_host, pstat_rolling, pstat_microstate, pstat_chain_state,
+ * pstat_chain_extras, pstat_checkpoint) it fails with PSTAT_ERR_HIP if a launch since the last successful
+ * call did not run to completion (a job of the persistent kernels timed out waiting for its predecessor):
+ * the handle's averages are then not the averages of the steps it was asked for. */
 int pstat_summary_get(pstat_handle *h, int32_t icase, pstat_summary *out);
 
 /* Turns already-merged reduction vectors (host memory, PSTAT_NRED doubles, e.g. after an
@@ -213,6 +233,13 @@ int pstat_summary_from_reduction(const double red[PSTAT_NRED], int64_t steps_per
 int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles /* [2n] */,
                       double sums[PSTAT_NOBS], int64_t counters[4], double steps[3],
                       uint32_t rng[4]);
+
+/* Per-chain running means of case `icase` (all cases if < 0), host memory: out[q * nchains + k], q < PSTAT_NQ in the
+ * order of the reduction vector (16 observables, acceptance ratio, the clustering main's two extras), k counting
+ * the chains of that case.  This is what the device reduction folds; a host that honours --numeric-type
+ * (mcmc_eap_chain.jl:186-197: Float128 / Dec128 / BigFloat averagers) merges these in its own wide type -- the
+ * per-chain sums themselves are Float64 on the device, like the reference's default.  Synchronises. */
+int pstat_chain_means(pstat_handle *h, int32_t icase, double *out /* [PSTAT_NQ][nchains] */);
 
 /* Start every chain over from a given configuration, as EAPChain(pargs) does with --x0/--dx0
  * (inc/eap_chain.jl:61-79): x0 holds [phi; theta] (len 2: every monomer) or the interleaved

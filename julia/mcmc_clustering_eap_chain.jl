@@ -10,6 +10,7 @@
 #         --num-chains 16384 --prefix out/run1 -v 2
 using ArgParse
 using Logging
+using Random
 
 const LIBPSTAT = get(ENV, "PSTAT_LIB", joinpath(@__DIR__, "..", "polymer_stats_amd", "libpstat.so"))
 
@@ -34,7 +35,11 @@ struct PstatSummary
   acceptance_ratio::Cdouble; ar_stderr::Cdouble
   num_chains::Int64; steps_per_chain::Int64; attempted_updates::Cdouble
   extra_avg::NTuple{2,Cdouble}; extra_stderr::NTuple{2,Cdouble}
+  nan_rejects::Int64; chains_collapsed::Int64
 end
+
+const NQ = 19                   # PSTAT_NQ
+const NRED = 1 + 2 * NQ + 2     # PSTAT_NRED
 
 function check(rc::Cint)
   if rc != 0
@@ -82,13 +87,19 @@ s = ArgParseSettings();
   "--profile", "-Z";       action = :store_true
   # added by this implementation
   "--num-chains";          arg_type = Int;     default = 4096
-  "--seed";                arg_type = Int;     default = 0
+  "--seed";                arg_type = Int;     default = -1;  help = "seed of the per-chain generators; default (-1): fresh OS entropy per run, like the reference's unseeded RNG"
   "--devices";             arg_type = String;  default = "0"
   "--precision";           arg_type = String;  default = "f32"
   "--rng";                 arg_type = String;  default = "mwc64x"
 end
 
 pargs = parse_args(s);
+# The reference never seeds Julia's RNG: the same command line launched 25 times gives 25 independent samples
+# (run/interacting-compare-with-clustering_2021-09-28.jl:26-27).  Same here unless --seed is given.
+const SEED_WAS_DRAWN = pargs["seed"] < 0
+if SEED_WAS_DRAWN
+  pargs["seed"] = Int(rand(RandomDevice(), UInt64) >> 1)
+end
 
 if pargs["verbose"] == 3
   global_logger(ConsoleLogger(stderr, Logging.Info));
@@ -99,6 +110,8 @@ elseif pargs["verbose"] == 1
 else
   global_logger(Logging.NullLogger());
 end
+SEED_WAS_DRAWN && pargs["verbose"] >= 2 &&
+  println(stderr, "[ Info: seed: $(pargs["seed"]) (fresh entropy; pass --seed $(pargs["seed"]) to reproduce this run)");
 
 # --x0 / --dx0 exactly as EAPChain(pargs) reads them (inc/eap_chain.jl:61-79)
 function start_configuration(pargs)
@@ -134,9 +147,45 @@ function params(pargs, num_chains, chain_id0, device, x0, dx0)
               uniform_x0 ? 1 : 0, 0, pargs["cutoff-radius"])
 end
 
+# --numeric-type (mcmc_eap_chain.jl:186-197): the per-chain sums are Float64 on the device (the reference's default);
+# the option selects the type in which the per-chain means are merged.  Float128 / Dec128 need Quadmath / DecFP,
+# as in the reference.
+function wide_type(name)
+  name == "float64" && return Float64
+  name == "big" && return BigFloat
+  if name == "float128"
+    @eval using Quadmath
+    return Base.invokelatest(() -> Quadmath.Float128)
+  end
+  @eval using DecFP
+  return Base.invokelatest(() -> DecFP.Dec128)
+end
+
+# pooled mean and across-chain standard error of the NQ per-chain running means, in type T
+function wide_merge(handles, num_chains_of, T)
+  cols = Vector{Matrix{Float64}}()
+  for (h, m) in zip(handles, num_chains_of)
+    buf = zeros(Cdouble, m, NQ)      # column-major: [chain, quantity] = out[q * nchains + k]
+    check(ccall((:pstat_chain_means, LIBPSTAT), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}), h, -1, buf))
+    push!(cols, buf)
+  end
+  all = vcat(cols...)
+  C = size(all, 1)
+  mean = [sum(T.(all[:, q])) / C for q = 1:NQ]
+  se = [C > 1 ? sqrt(sum((T.(all[:, q]) .- mean[q]) .^ 2) / (C - 1) / C) : zero(T) for q = 1:NQ]
+  return mean, se
+end
+
+function report_failures(sm)
+  sm.nan_rejects > 0 &&
+    @warn "$(sm.nan_rejects) proposals had a non-finite energy and were rejected";
+  sm.chains_collapsed > 0 &&
+    @warn "$(sm.chains_collapsed) of $(sm.num_chains) chains have collapsed (|U| > 1e6 n kT: monomers on top of each other)";
+end
+
 function pooled_summary(handles, steps)
-  red = zeros(Cdouble, 39)
-  tmp = zeros(Cdouble, 39)
+  red = zeros(Cdouble, NRED)
+  tmp = zeros(Cdouble, NRED)
   for h in handles
     check(ccall((:pstat_reduce_host, LIBPSTAT), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}), h, -1, tmp))
     red .+= tmp
@@ -232,6 +281,7 @@ function mcmc(nsteps::Int, pargs, handles, kT; write_files::Bool)
   sm = pooled_summary(handles, nsteps)
   @info "total time elapsed: $(time() - start)";
   @info "acceptance rate: $(sm.acceptance_ratio)";
+  report_failures(sm);
   if write_files; close(outfile); close(rollfile); end
   return sm
 end
@@ -245,13 +295,28 @@ else
     mcmc(pargs["burn-in"], pargs, handles, pargs["kT"] * kT_mult; write_files = false)
   end
   result = mcmc(pargs["num-steps"], pargs, handles, pargs["kT"]; write_files = true)   # :385-386
+  if pargs["numeric-type"] != "float64"
+    T = wide_type(pargs["numeric-type"])
+    @warn "--numeric-type $(pargs["numeric-type"]): per-chain sums are Float64 on the device; the merge over chains is carried out in $T";
+    counts = Int[]
+    for h in handles   # chains held by each handle: entry [0] of its reduction vector
+      tmp = zeros(Cdouble, NRED)
+      check(ccall((:pstat_reduce_host, LIBPSTAT), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}), h, -1, tmp))
+      push!(counts, Int(round(tmp[1])))
+    end
+    (wmean, _) = wide_merge(handles, counts, T)
+    global WIDE = wmean
+  end
   for h in handles
     ccall((:pstat_destroy, LIBPSTAT), Cvoid, (Ptr{Cvoid},), h)
   end
   result
 end
 
-a = collect(sm.avg); x = collect(sm.extra_avg)
+a = collect(sm.avg); x = collect(sm.extra_avg); ar = sm.acceptance_ratio
+if @isdefined WIDE
+  a = WIDE[1:16]; ar = WIDE[17]; x = WIDE[18:19]
+end
 println("<r>    =   $(a[1:3])");
 println("<r/nb> =   $(a[1:3] / (pargs["mlen"]*pargs["num-monomers"]))");
 println("<rj2>  =   $(a[4:6])");
@@ -263,4 +328,4 @@ println("<U>    =   $(a[15])");
 println("<U2>   =   $(a[16])");
 println("<cos2(θ)>   =   $(x[1])");
 println("<ψ>    =   $(x[2])");
-println("AR     =   $(sm.acceptance_ratio)");
+println("AR     =   $ar");

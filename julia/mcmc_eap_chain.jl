@@ -9,6 +9,7 @@
 #         --num-chains 65536 --prefix out/run1 -v 2
 using ArgParse
 using Logging
+using Random
 using Printf
 
 const LIBPSTAT = get(ENV, "PSTAT_LIB", joinpath(@__DIR__, "..", "polymer_stats_amd", "libpstat.so"))
@@ -35,7 +36,11 @@ struct PstatSummary
   acceptance_ratio::Cdouble; ar_stderr::Cdouble
   num_chains::Int64; steps_per_chain::Int64; attempted_updates::Cdouble
   extra_avg::NTuple{2,Cdouble}; extra_stderr::NTuple{2,Cdouble}
+  nan_rejects::Int64; chains_collapsed::Int64
 end
+
+const NQ = 19                   # PSTAT_NQ
+const NRED = 1 + 2 * NQ + 2     # PSTAT_NRED
 
 function check(rc::Cint)
   if rc != 0
@@ -83,7 +88,7 @@ s = ArgParseSettings();
   "--profile", "-Z";       action = :store_true
   # added by this implementation
   "--num-chains";          arg_type = Int;     default = 4096
-  "--seed";                arg_type = Int;     default = 0
+  "--seed";                arg_type = Int;     default = -1;  help = "seed of the per-chain generators; default (-1): fresh OS entropy per run, like the reference's unseeded RNG"
   "--devices";             arg_type = String;  default = "0"
   "--precision";           arg_type = String;  default = "f32"
   "--rng";                 arg_type = String;  default = "mwc64x"
@@ -92,6 +97,12 @@ s = ArgParseSettings();
 end
 
 pargs = parse_args(s);
+# The reference never seeds Julia's RNG: the same command line launched 25 times gives 25 independent samples
+# (run/interacting-compare-with-clustering_2021-09-28.jl:26-27).  Same here unless --seed is given.
+const SEED_WAS_DRAWN = pargs["seed"] < 0
+if SEED_WAS_DRAWN
+  pargs["seed"] = Int(rand(RandomDevice(), UInt64) >> 1)
+end
 
 if pargs["verbose"] == 3
   global_logger(ConsoleLogger(stderr, Logging.Info));
@@ -102,6 +113,8 @@ elseif pargs["verbose"] == 1
 else
   global_logger(Logging.NullLogger());
 end
+SEED_WAS_DRAWN && pargs["verbose"] >= 2 &&
+  println(stderr, "[ Info: seed: $(pargs["seed"]) (fresh entropy; pass --seed $(pargs["seed"]) to reproduce this run)");
 
 function params(pargs, num_chains, chain_id0, device)
   ct = get(Dict("dielectric" => 0, "polar" => 1), pargs["chain-type"], -1)
@@ -122,9 +135,45 @@ function params(pargs, num_chains, chain_id0, device)
               0, 0, 7.5)
 end
 
+# --numeric-type (mcmc_eap_chain.jl:186-197): the per-chain sums are Float64 on the device (the reference's default);
+# the option selects the type in which the per-chain means are merged.  Float128 / Dec128 need Quadmath / DecFP,
+# as in the reference.
+function wide_type(name)
+  name == "float64" && return Float64
+  name == "big" && return BigFloat
+  if name == "float128"
+    @eval using Quadmath
+    return Base.invokelatest(() -> Quadmath.Float128)
+  end
+  @eval using DecFP
+  return Base.invokelatest(() -> DecFP.Dec128)
+end
+
+# pooled mean and across-chain standard error of the NQ per-chain running means, in type T
+function wide_merge(handles, num_chains_of, T)
+  cols = Vector{Matrix{Float64}}()
+  for (h, m) in zip(handles, num_chains_of)
+    buf = zeros(Cdouble, m, NQ)      # column-major: [chain, quantity] = out[q * nchains + k]
+    check(ccall((:pstat_chain_means, LIBPSTAT), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}), h, -1, buf))
+    push!(cols, buf)
+  end
+  all = vcat(cols...)
+  C = size(all, 1)
+  mean = [sum(T.(all[:, q])) / C for q = 1:NQ]
+  se = [C > 1 ? sqrt(sum((T.(all[:, q]) .- mean[q]) .^ 2) / (C - 1) / C) : zero(T) for q = 1:NQ]
+  return mean, se
+end
+
+function report_failures(sm)
+  sm.nan_rejects > 0 &&
+    @warn "$(sm.nan_rejects) proposals had a non-finite energy and were rejected";
+  sm.chains_collapsed > 0 &&
+    @warn "$(sm.chains_collapsed) of $(sm.num_chains) chains have collapsed (|U| > 1e6 n kT: monomers on top of each other)";
+end
+
 function pooled_summary(handles, steps)
-  red = zeros(Cdouble, 39)
-  tmp = zeros(Cdouble, 39)
+  red = zeros(Cdouble, NRED)
+  tmp = zeros(Cdouble, NRED)
   for h in handles
     check(ccall((:pstat_reduce_host, LIBPSTAT), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}), h, -1, tmp))
     red .+= tmp
@@ -146,6 +195,7 @@ function mcmc(nsteps::Int, pargs)
   devices = [parse(Int, d) for d in split(pargs["devices"], ",") if d != ""]
   total = pargs["num-chains"]
   handles = Ptr{Cvoid}[]
+  counts = Int[]
   first = 0
   for (i, dev) in enumerate(devices)
     cnt = div(total, length(devices)) + (i <= rem(total, length(devices)) ? 1 : 0)
@@ -155,6 +205,7 @@ function mcmc(nsteps::Int, pargs)
     check(ccall((:pstat_create, LIBPSTAT), Cint, (Ref{PstatParams}, Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
                 p, 1, C_NULL, h))
     push!(handles, h[])
+    push!(counts, cnt)
     first += cnt
   end
 
@@ -209,13 +260,21 @@ function mcmc(nsteps::Int, pargs)
   sm = pooled_summary(handles, recorded)
   @info "total time elapsed: $(time() - start)";
   @info "acceptance rate: $(sm.acceptance_ratio)";
+  report_failures(sm);
   close(outfile); close(rollfile);
+  a = collect(sm.avg)
+  ar = sm.acceptance_ratio
+  if pargs["numeric-type"] != "float64"
+    T = wide_type(pargs["numeric-type"])
+    @warn "--numeric-type $(pargs["numeric-type"]): per-chain sums are Float64 on the device; the merge over chains is carried out in $T";
+    (wmean, _) = wide_merge(handles, counts, T)
+    a = wmean[1:NOBS]; ar = wmean[NOBS + 1]
+  end
   for h in handles
     ccall((:pstat_destroy, LIBPSTAT), Cvoid, (Ptr{Cvoid},), h)
   end
-  a = collect(sm.avg)
   # (scalar averages r2, p2, U, U2), (vector averages r, rj2, p, pj2), acceptance ratio
-  return ([a[7], a[14], a[15], a[16]], [a[1:3], a[4:6], a[8:10], a[11:13]], sm.acceptance_ratio)
+  return ([a[7], a[14], a[15], a[16]], [a[1:3], a[4:6], a[8:10], a[11:13]], ar)
 end
 
 (sas, vas, ar) = if pargs["profile"]

@@ -14,7 +14,9 @@ F32, F64, Q16 = 0, 1, 2
 RNG_MWC64X, RNG_XOSHIRO128PP = 0, 1
 NOBS = 16
 NQ = 19
-NRED = 1 + 2 * NQ
+NX = 2
+NRED = 1 + 2 * NQ + NX
+MWC64X_MAX_CHAINS = 1 << 22
 MOVES_SINGLE, MOVES_CLUSTER = 0, 1
 OBS_NAMES = ["r1", "r2", "r3", "r1sq", "r2sq", "r3sq", "rsq",
              "p1", "p2", "p3", "p1sq", "p2sq", "p3sq", "psq", "U", "Usq"]
@@ -25,8 +27,9 @@ SYMBOLS = [
     "pstat_default_params", "pstat_create", "pstat_destroy", "pstat_advance", "pstat_sync",
     "pstat_reinit", "pstat_reset_averages", "pstat_set_kT", "pstat_scale_kT", "pstat_reset_sampler", "pstat_reduce_device", "pstat_reduce_host", "pstat_rolling", "pstat_microstate",
     "pstat_summary_get", "pstat_summary_from_reduction", "pstat_chain_state", "pstat_chain_extras", "pstat_restart_from_x0",
-    "pstat_checkpoint", "pstat_restore", "pstat_launch_info_get",
+    "pstat_checkpoint", "pstat_restore", "pstat_launch_info_get", "pstat_chain_means",
 ]
+ABI_VERSION = 5
 
 
 class PstatError(RuntimeError):
@@ -53,7 +56,8 @@ class Summary(C.Structure):
                 ("acceptance_ratio", C.c_double), ("ar_stderr", C.c_double),
                 ("num_chains", C.c_int64), ("steps_per_chain", C.c_int64),
                 ("attempted_updates", C.c_double),
-                ("extra_avg", C.c_double * 2), ("extra_stderr", C.c_double * 2)]
+                ("extra_avg", C.c_double * 2), ("extra_stderr", C.c_double * 2),
+                ("nan_rejects", C.c_int64), ("chains_collapsed", C.c_int64)]
 
 
 class LaunchInfo(C.Structure):
@@ -104,6 +108,10 @@ def load():
     L.pstat_checkpoint.argtypes = [vp, vp, C.POINTER(C.c_size_t)]
     L.pstat_restore.argtypes = [vp, vp, C.c_size_t]
     L.pstat_launch_info_get.argtypes = [vp, C.POINTER(LaunchInfo)]
+    L.pstat_chain_means.argtypes = [vp, i32, dp]
+    if L.pstat_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.pstat_abi_version()}, this binding needs {ABI_VERSION}: "
+                          "rebuild it with `make -C polymer_stats_amd/csrc`")
     _lib = L
     return L
 

@@ -36,7 +36,7 @@ int fail(int code, const char *fmt, ...) {
       return fail(PSTAT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));          \
   } while (0)
 
-constexpr uint64_t CKPT_MAGIC = 0x5053544154434b32ull;  // "PSTATCK2" (v2: 64-bit adaptation windows, two more observables)
+constexpr uint64_t CKPT_MAGIC = 0x5053544154434b33ull;  // "PSTATCK3" (v3: + the non-finite-energy rejection counters)
 
 struct Buffer {
   void *ptr = nullptr;
@@ -65,6 +65,7 @@ struct pstat_handle {
   int64_t steps_recorded = 0;       // steps every chain has recorded so far (all inits)
   int64_t step_in_init = 0;         // the reference's loop variable `step` (mcmc_eap_chain.jl:276)
   size_t elem = 4;                  // sizeof(R)
+  int failed_job = 0;               // sticky: 1 + the job of a persistent launch that timed out (0 = none)
 };
 
 namespace {
@@ -105,6 +106,13 @@ int validate(const pstat_params *c, int ncases) {
   if (b.rng != PSTAT_RNG_MWC64X && b.rng != PSTAT_RNG_XOSHIRO128PP)
     return fail(PSTAT_ERR_INVALID_ARG, "rng must be PSTAT_RNG_MWC64X or PSTAT_RNG_XOSHIRO128PP");
   if (b.reserved != 0) return fail(PSTAT_ERR_INVALID_ARG, "reserved field must be 0");
+  if (b.rng == PSTAT_RNG_MWC64X)
+    for (int i = 0; i < ncases; ++i)
+      if (c[i].chain_id0 > PSTAT_MWC64X_MAX_CHAINS || (uint64_t)b.num_chains > PSTAT_MWC64X_MAX_CHAINS - c[i].chain_id0)
+        return fail(PSTAT_ERR_INVALID_ARG, "MWC64X streams are disjoint only for global chain ids < 2^22 (chain k starts "
+                    "k * 2^40 outputs down one sequence of period ~2^63): chain_id0 + num_chains = %llu + %lld exceeds "
+                    "that (case %d); use PSTAT_RNG_XOSHIRO128PP for larger ids",
+                    (unsigned long long)c[i].chain_id0, (long long)b.num_chains, i);
   if (b.move_set != PSTAT_MOVES_SINGLE && b.move_set != PSTAT_MOVES_CLUSTER)
     return fail(PSTAT_ERR_INVALID_ARG, "move_set must be PSTAT_MOVES_SINGLE or PSTAT_MOVES_CLUSTER");
   if (b.move_set == PSTAT_MOVES_CLUSTER) {
@@ -154,12 +162,34 @@ int set_device(pstat_handle *h) {
   return PSTAT_OK;
 }
 
+int report_failed_job(pstat_handle *h) {
+  int q[10] = {0};
+  (void)hipMemcpy(q, h->d_queue, sizeof q, hipMemcpyDeviceToHost);
+  return fail(PSTAT_ERR_HIP, "a persistent launch did not complete: job %d waited too long for its predecessor "
+              "(queue head %d, done[0..7] = %d %d %d %d %d %d %d %d); the handle's averages are not those of the "
+              "steps asked for", h->failed_job - 1, q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9]);
+}
+
+// Waits for the handle's stream and then looks at the error word of the persistent kernels' job queue
+// (run_job_queue, pstat_device.h).  The word is never cleared by a launch and the failure is sticky on
+// the handle: every entry point that hands results to the caller goes through here.
+int sync_checked(pstat_handle *h) {
+  if (h->failed_job) return report_failed_job(h);
+  int flag = 0;
+  HIP_TRY(hipMemcpyAsync(&flag, h->d_queue, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (flag) {
+    h->failed_job = flag;
+    return report_failed_job(h);
+  }
+  return PSTAT_OK;
+}
+
 int reduce_to_host(pstat_handle *h, int icase, double red[PSTAT_NRED]) {
   int rc = pstat_reduce_device(h, icase, h->d_red);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(red, h->d_red, sizeof(double) * PSTAT_NRED, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return PSTAT_OK;
+  return sync_checked(h);
 }
 
 }  // namespace
@@ -325,6 +355,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_TRY(alloc(h, (void **)&S.wnorm, Cz * sizeof(double)));
   CREATE_TRY(alloc(h, (void **)&S.lag, Cz * sizeof(double)));
   CREATE_TRY(alloc(h, (void **)&S.uref, Cz * sizeof(double)));
+  CREATE_TRY(alloc(h, (void **)&S.nanrej, Cz * sizeof(int64_t)));
   const size_t nstate = h->bufs.size();
   CREATE_TRY(alloc(h, &S.ang_tmp, 2 * n * Cz * h->elem));
   CREATE_TRY(alloc(h, (void **)&h->d_cases, sizeof(CaseConst) * (size_t)ncases));
@@ -392,6 +423,7 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
   if (nsteps == 0) return PSTAT_OK;
   int rc = set_device(h);
   if (rc) return rc;
+  if (h->failed_job) return report_failed_job(h);
   const int64_t max_launch = 1ll << 30;  // per-launch step counters are 32-bit
   if (all_pairs(h->base.energy_type)) {
     while (nsteps > 0) {
@@ -450,26 +482,11 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
   return PSTAT_OK;
 }
 
-static int check_queue_error(pstat_handle *h) {
-  int flag = 0;
-  HIP_TRY(hipMemcpyAsync(&flag, h->d_queue + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  if (flag) {
-    int q[10] = {0};
-    (void)hipMemcpy(q, h->d_queue, sizeof q, hipMemcpyDeviceToHost);
-    return fail(PSTAT_ERR_HIP, "sweep kernel: job %d waited too long for its predecessor "
-                "(queue head %d, done[0..7] = %d %d %d %d %d %d %d %d)", flag - 1, q[0], q[2], q[3], q[4],
-                q[5], q[6], q[7], q[8], q[9]);
-  }
-  return PSTAT_OK;
-}
-
 int pstat_sync(pstat_handle *h) {
   if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
   int rc = set_device(h);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return check_queue_error(h);
+  return sync_checked(h);
 }
 
 int pstat_reinit(pstat_handle *h, int32_t force_init) {
@@ -499,6 +516,7 @@ int pstat_reset_averages(pstat_handle *h) {
   HIP_TRY(hipMemsetAsync(h->S.sums, 0, NSUMS * C * sizeof(double), h->stream));
   HIP_TRY(hipMemsetAsync(h->S.wnorm, 0, C * sizeof(double), h->stream));
   HIP_TRY(hipMemsetAsync(h->S.nacc_total, 0, C * sizeof(int64_t), h->stream));
+  HIP_TRY(hipMemsetAsync(h->S.nanrej, 0, C * sizeof(int64_t), h->stream));
   h->steps_recorded = 0;
   return PSTAT_OK;
 }
@@ -579,7 +597,8 @@ int pstat_reduce_device(pstat_handle *h, int32_t icase, double *dev_out) {
   const int64_t per = h->base.num_chains;
   const int64_t c0 = icase < 0 ? 0 : icase * per;
   const int64_t c1 = icase < 0 ? h->S.C : c0 + per;
-  HIP_TRY(launch_reduce(h->S, c0, c1, h->steps_recorded, h->cfg.umbrella, h->d_partial, dev_out, h->stream));
+  HIP_TRY(launch_reduce(h->S, c0, c1, h->steps_recorded, h->cfg.umbrella, h->d_cases, h->base.num_chains, h->base.n,
+                        h->d_partial, dev_out, h->stream));
   return PSTAT_OK;
 }
 
@@ -608,6 +627,8 @@ int pstat_summary_from_reduction(const double red[PSTAT_NRED], int64_t steps_per
     else if (q == PSTAT_NOBS) { out->acceptance_ratio = mean; out->ar_stderr = se; }
     else { out->extra_avg[q - PSTAT_NOBS - 1] = mean; out->extra_stderr[q - PSTAT_NOBS - 1] = se; }
   }
+  out->nan_rejects = (int64_t)std::llround(red[1 + 2 * PSTAT_NQ]);
+  out->chains_collapsed = (int64_t)std::llround(red[2 + 2 * PSTAT_NQ]);
   return PSTAT_OK;
 }
 
@@ -637,8 +658,7 @@ int pstat_microstate(pstat_handle *h, int64_t chain, double out[7]) {
   // obs is [NOBS_STATE][C]: a strided gather of 7 doubles
   HIP_TRY(hipMemcpy2DAsync(out, sizeof(double), h->S.obs + chain, sizeof(double) * (size_t)h->S.C,
                            sizeof(double), 7, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return PSTAT_OK;
+  return sync_checked(h);
 }
 
 int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sums[PSTAT_NOBS],
@@ -648,7 +668,8 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sum
   int rc = set_device(h);
   if (rc) return rc;
   const size_t C = (size_t)h->S.C, n = (size_t)h->base.n;
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = sync_checked(h);
+  if (rc) return rc;
   if (angles) {
     std::unique_ptr<unsigned char[]> tmp(new (std::nothrow) unsigned char[2 * n * h->elem]);
     if (!tmp) return fail(PSTAT_ERR_NOMEM, "host allocation failed");
@@ -695,13 +716,54 @@ int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles, double sum
   return PSTAT_OK;
 }
 
+int pstat_chain_means(pstat_handle *h, int32_t icase, double *out) {
+  if (!h || !out) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
+  if (icase >= h->ncases) return fail(PSTAT_ERR_INVALID_ARG, "case %d out of range", icase);
+  int rc = set_device(h);
+  if (rc) return rc;
+  rc = sync_checked(h);
+  if (rc) return rc;
+  const size_t C = (size_t)h->S.C, per = (size_t)h->base.num_chains;
+  const size_t c0 = icase < 0 ? 0 : (size_t)icase * per, m = icase < 0 ? C : per;
+  try {
+    std::vector<double> sums((size_t)NSUMS * m), wn(m);
+    std::vector<int64_t> nacc(m);
+    HIP_TRY(hipMemcpy2D(sums.data(), m * sizeof(double), h->S.sums + c0, C * sizeof(double), m * sizeof(double), NSUMS,
+                        hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(nacc.data(), h->S.nacc_total + c0, m * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (h->cfg.umbrella) HIP_TRY(hipMemcpy(wn.data(), h->S.wnorm + c0, m * sizeof(double), hipMemcpyDeviceToHost));
+    const double steps = (double)h->steps_recorded;
+    // same arithmetic as reduce_stage1 (pstat_kernels.hip)
+    static const int src[PSTAT_NOBS] = {S_R1, S_R2, S_R3, S_R1SQ, S_R2SQ, S_R3SQ, -1, S_P1, S_P2, S_P3,
+                                        S_P1SQ, S_P2SQ, S_P3SQ, -2, S_U, S_USQ};
+    for (size_t k = 0; k < m; ++k) {
+      const double norm = h->cfg.umbrella ? wn[k] : steps;
+      const double inv = norm != 0.0 ? 1.0 / norm : 0.0;
+      for (int q = 0; q < PSTAT_NOBS; ++q) {
+        double v;
+        if (src[q] == -1) v = sums[S_R1SQ * m + k] + sums[S_R2SQ * m + k] + sums[S_R3SQ * m + k];
+        else if (src[q] == -2) v = sums[S_P1SQ * m + k] + sums[S_P2SQ * m + k] + sums[S_P3SQ * m + k];
+        else v = sums[(size_t)src[q] * m + k];
+        out[(size_t)q * m + k] = v * inv;
+      }
+      out[16 * m + k] = steps > 0 ? (double)nacc[k] / steps : 0.0;
+      out[17 * m + k] = sums[S_C2 * m + k] * inv;
+      out[18 * m + k] = sums[S_PSI * m + k] * inv;
+    }
+  } catch (const std::bad_alloc &) {
+    return fail(PSTAT_ERR_NOMEM, "host allocation failed");
+  }
+  return PSTAT_OK;
+}
+
 int pstat_chain_extras(pstat_handle *h, int64_t chain, double extra_sums[2], double extra_now[2]) {
   if (!h) return fail(PSTAT_ERR_INVALID_ARG, "null handle");
   if (chain < 0 || chain >= h->S.C) return fail(PSTAT_ERR_INVALID_ARG, "chain out of range");
   int rc = set_device(h);
   if (rc) return rc;
   const size_t C = (size_t)h->S.C;
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = sync_checked(h);
+  if (rc) return rc;
   if (extra_sums)
     HIP_TRY(hipMemcpy2D(extra_sums, sizeof(double), h->S.sums + (size_t)S_C2 * C + chain, C * sizeof(double),
                         sizeof(double), 2, hipMemcpyDeviceToHost));
@@ -713,13 +775,13 @@ int pstat_chain_extras(pstat_handle *h, int64_t chain, double extra_sums[2], dou
   return PSTAT_OK;
 }
 
-// checkpoint image: header, then the ten state buffers in allocation order
+// checkpoint image: header, then the eleven state buffers in allocation order
 struct CkptHeader {
   uint64_t magic;
   int64_t n, C, ncases, steps_recorded, step_in_init;
   int32_t precision, chain_type, energy_type, reserved;
 };
-static const int kStateBuffers = 10;
+static const int kStateBuffers = 11;
 
 int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes) {
   if (!h || !bytes) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
@@ -729,7 +791,8 @@ int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes) {
   if (*bytes < need) { *bytes = need; return fail(PSTAT_ERR_TOO_SMALL, "checkpoint needs %zu bytes", need); }
   int rc = set_device(h);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  rc = sync_checked(h);
+  if (rc) return rc;
   CkptHeader hd{CKPT_MAGIC, h->base.n, h->S.C, h->ncases, h->steps_recorded, h->step_in_init,
                 h->base.precision, h->base.chain_type, h->base.energy_type, h->cfg.lag};
   char *q = (char *)buf;

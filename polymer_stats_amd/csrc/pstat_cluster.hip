@@ -122,6 +122,7 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
   R phistep = (R)(phistep_d / ph_unit), thstep = (R)(thstep_d / th_unit);
   int64_t nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
+  int nnan_seg = 0;   // proposals with a non-finite energy difference (Ising pair terms at r -> 0)
   R Orx = (R)S.obs[OBS_R1 * C + c], Ory = (R)S.obs[OBS_R2 * C + c], Orz = (R)S.obs[OBS_R3 * C + c];
   R Opx = (R)S.obs[OBS_P1 * C + c], Opy = (R)S.obs[OBS_P2 * C + c], Opz = (R)S.obs[OBS_P3 * C + c];
   R OU = (R)S.obs[OBS_U * C + c];
@@ -408,6 +409,7 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
       }
 
       ok = ok && !edge && inside;
+      if constexpr (EN == PSTAT_ISING) nnan_seg += not_finite(dU) ? 1 : 0;
 
       // ---- commit
       if (ok) {
@@ -502,6 +504,7 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
   S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
   S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
   S.nacc_total[c] += nacc_seg;
+  if constexpr (EN == PSTAT_ISING) S.nanrej[c] += nnan_seg;
   S.obs[OBS_R1 * C + c] = Orx; S.obs[OBS_R2 * C + c] = Ory; S.obs[OBS_R3 * C + c] = Orz;
   S.obs[OBS_P1 * C + c] = Opx; S.obs[OBS_P2 * C + c] = Opy; S.obs[OBS_P3 * C + c] = Opz;
   S.obs[OBS_U * C + c] = OU; S.obs[OBS_USUM * C + c] = usum;
@@ -584,7 +587,7 @@ hipError_t launch_cluster(const LaunchCfg &cfg, const SweepArgs &a, const DevSta
   const int lds = cluster_lds_bytes(cfg, a);
   hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(queue, 0, sizeof(int) * sweep_queue_ints(a), stream);
+  e = hipMemsetAsync(queue + 1, 0, sizeof(int) * (sweep_queue_ints(a) - 1), stream);   // queue[0]: sticky error word
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a, s, cases, cfg.umbrella, queue);
   return hipGetLastError();

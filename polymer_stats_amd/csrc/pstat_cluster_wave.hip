@@ -167,6 +167,7 @@ void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ 
   R phistep = (R)(phistep_d / AG::unit), thstep = (R)(thstep_d / AG::unit);
   int64_t nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
+  int nnan_seg = 0;   // proposals whose trial energy was NaN or +-Inf (1/r^3 at r -> 0)
   R lag = (R)S.lag[c];
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
   const R uref = umb ? (R)S.uref[c] : (R)0;
@@ -276,6 +277,7 @@ void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ 
       const R dlt = -(tr.U - cur.U) / kT + domega + dw + cw_log(alpha) - lag;
       bool ok = ((dlt >= 0) || (eps < exp_r(dlt))) && !edge;
       ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
+      nnan_seg += not_finite(tr.U) ? 1 : 0;
       if (ok) {
         cur = tr;
         lag = cw_log(alpha);
@@ -341,6 +343,7 @@ void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ 
     S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
     S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
     S.nacc_total[c] += nacc_seg;
+    S.nanrej[c] += nnan_seg;
     S.obs[OBS_R1 * C + c] = cur.rx; S.obs[OBS_R2 * C + c] = cur.ry; S.obs[OBS_R3 * C + c] = cur.rz;
     S.obs[OBS_P1 * C + c] = cur.px; S.obs[OBS_P2 * C + c] = cur.py; S.obs[OBS_P3 * C + c] = cur.pz;
     S.obs[OBS_U * C + c] = cur.U; S.obs[OBS_USUM * C + c] = cur.usum;

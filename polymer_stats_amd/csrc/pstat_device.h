@@ -37,6 +37,8 @@ struct DevState {
   double *uref;         // f64[C]         sum(u) of the chain's first configuration: the umbrella weights
                         //                are taken relative to it (a per-chain constant factor cancels
                         //                in value/normalizer, inc/average.jl:38,63-67)
+  int64_t *nanrej;      // i64[C]         proposals whose trial energy was NaN or +-Inf (1/r^3 singularities of the
+                        //                pair energies; the reference rejects them silently, inc/acceptance.jl:29-39)
   int64_t C;
 };
 
@@ -199,7 +201,7 @@ __device__ __forceinline__ void run_job_queue(const SweepArgs &A, int *__restric
                                               const CaseConst *__restrict__ cases) {
   const int nblocks = (int)(A.blocks_per_case * A.ncases);
   const int njobs = nblocks * A.nseg;
-  int *head = queue, *error = queue + 1, *done = queue + 2;
+  int *error = queue, *head = queue + 1, *done = queue + 2;   // the error word is sticky: launches clear queue[1..]
   bool failed = false;
   while (!failed) {
     int job = 0;
@@ -262,9 +264,12 @@ hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState
 size_t sweep_queue_ints(const SweepArgs &a);
 hipError_t launch_reinit(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                          const CaseConst *cases, int force_init, hipStream_t stream);
+// true iff x is NaN or +-Inf (one v_cmp_class)
+template <typename R> __host__ __device__ inline bool not_finite(R x) { return !__builtin_isfinite(x); }
 // reduction of chains [c0, c1) into out[PSTAT_NRED]; partial = scratch of reduce_scratch_doubles()
 hipError_t launch_reduce(const DevState &s, int64_t c0, int64_t c1, int64_t steps_recorded,
-                         int umbrella, double *partial, double *out, hipStream_t stream);
+                         int umbrella, const CaseConst *cases, int64_t chains_per_case, int64_t n,
+                         double *partial, double *out, hipStream_t stream);
 size_t reduce_scratch_doubles();
 // LDS bytes and kernel attributes of the sweep kernel chosen for cfg
 hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? 2 : (M == 2 ? PSTAT_
   R phistep = (R)(phistep_d / AG::unit), thstep = (R)(thstep_d / AG::unit);
   int64_t nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
+  int nnan_seg = 0;   // proposals whose trial energy was NaN or +-Inf (1/r^3 at r -> 0), rejected as in the reference
   R lag = use_lag ? (R)S.lag[c] : (R)0;
   // umbrella sampling (inc/average.jl:104-124), as in the sweep kernel: only w - w(first config) matters
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? 2 : (M == 2 ? PSTAT_
         ok = eps * st0 < st1 * e;
       }
       ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;   // one decision per chain
+      nnan_seg += not_finite(dU) ? 1 : 0;
       if (ok) {
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? 2 : (M == 2 ? PSTAT_
     S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
     S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
     S.nacc_total[c] += nacc_seg;
+    S.nanrej[c] += nnan_seg;
     S.obs[OBS_R1 * C + c] = rx; S.obs[OBS_R2 * C + c] = ry; S.obs[OBS_R3 * C + c] = rz;
     S.obs[OBS_P1 * C + c] = px; S.obs[OBS_P2 * C + c] = py; S.obs[OBS_P3 * C + c] = pz;
     S.obs[OBS_U * C + c] = U; S.obs[OBS_USUM * C + c] = usum;

@@ -107,6 +107,7 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
   S.wnorm[c] = 0.0;
   S.lag[c] = 0.0;
   S.uref[c] = usum;
+  S.nanrej[c] = 0;
   (void)omega;
 }
 
@@ -192,6 +193,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   R phistep = (R)(phistep_d / ph_unit), thstep = (R)(thstep_d / th_unit);
   int64_t nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
+  int nnan_seg = 0;   // proposals with a non-finite energy difference (only the pair energies can produce one)
   // observables O = (rx, ry | rz, px | py, pz | U, unused) as four 2-vectors (packed f32 math)
   R O[8];
   O[0] = (R)S.obs[OBS_R1 * C + c]; O[1] = (R)S.obs[OBS_R2 * C + c]; O[2] = (R)S.obs[OBS_R3 * C + c];
@@ -488,6 +490,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         lag = ok ? (R)0 : lag;
       }
       nacc_seg += ok ? 1 : 0;
+      if constexpr (EN == PSTAT_ISING) nnan_seg += not_finite(dU) ? 1 : 0;
       if (more) {  // forward the accepted angles into the prefetched row if it is the same monomer
         const bool same = dn.cell == d.cell;
         if constexpr (Q) an = same ? a1 : an;
@@ -595,6 +598,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   S.stepsz[0 * C + c] = phistep_d; S.stepsz[1 * C + c] = thstep_d;
   S.win[0 * C + c] = nacc_off + nacc_seg; S.win[1 * C + c] = natt_off + steps_seg;
   S.nacc_total[c] += nacc_seg;
+  if constexpr (EN == PSTAT_ISING) S.nanrej[c] += nnan_seg;
   const R unit_r = sizeof(R) == 4 ? b : (R)1;   // f32 carries r in units of b
   S.obs[OBS_R1 * C + c] = unit_r * Orxy.x; S.obs[OBS_R2 * C + c] = unit_r * Orxy.y; S.obs[OBS_R3 * C + c] = unit_r * Oz.x;
   S.obs[OBS_P1 * C + c] = Opxy.x; S.obs[OBS_P2 * C + c] = Opxy.y; S.obs[OBS_P3 * C + c] = Oz.y;
@@ -626,6 +630,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
 constexpr int RED_BLOCKS = 256;
 constexpr int RED_THREADS = 256;
 constexpr int NQ = 19;  // 16 observables + acceptance ratio + the clustering main's two extras
+constexpr int NX = 2;   // plain sums: non-finite-energy rejections, collapsed chains (pstat.h)
+constexpr int NP = 2 * NQ + NX;   // entries of one block's partial
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -636,9 +642,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 // stage 1: every block folds a strided slice of chains into partial[block][2*NQ] (deterministic)
 __global__ __launch_bounds__(RED_THREADS) void reduce_stage1(DevState S, int64_t c0, int64_t c1,
                                                              int64_t steps, int umbrella,
+                                                             const CaseConst *__restrict__ cases,
+                                                             int64_t chains_per_case, int64_t n,
                                                              double *__restrict__ partial) {
-  __shared__ double red[RED_THREADS / 64][2 * NQ];
-  double m1[NQ], m2[NQ];
+  __shared__ double red[RED_THREADS / 64][NP];
+  double m1[NQ], m2[NQ], mx[NX] = {0, 0};
 #pragma unroll
   for (int q = 0; q < NQ; ++q) { m1[q] = 0; m2[q] = 0; }
   const int64_t C = S.C;
@@ -663,6 +671,10 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_stage1(DevState S, int64_t
     v[18] = S.sums[S_PSI * C + c] * inv;   // mean bond angle
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { m1[q] += v[q]; m2[q] = fma(v[q], v[q], m2[q]); }
+    mx[0] += (double)S.nanrej[c];
+    // collapsed: |U| of the current configuration beyond anything separated monomers in a bounded field reach
+    const double Unow = S.obs[OBS_U * C + c];
+    mx[1] += !(fabs(Unow) <= 1e6 * (double)n * cases[c / chains_per_case].kT) ? 1.0 : 0.0;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -670,21 +682,26 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_stage1(DevState S, int64_t
     double a = wave_sum(m1[q]), b = wave_sum(m2[q]);
     if (lane == 0) { red[wave][q] = a; red[wave][NQ + q] = b; }
   }
+#pragma unroll
+  for (int q = 0; q < NX; ++q) {
+    double a = wave_sum(mx[q]);
+    if (lane == 0) red[wave][2 * NQ + q] = a;
+  }
   __syncthreads();
-  if (threadIdx.x < 2 * NQ) {
+  if (threadIdx.x < NP) {
     double t = 0;
 #pragma unroll
     for (int w = 0; w < RED_THREADS / 64; ++w) t += red[w][threadIdx.x];
-    partial[blockIdx.x * 2 * NQ + threadIdx.x] = t;
+    partial[blockIdx.x * NP + threadIdx.x] = t;
   }
 }
 
 // stage 2: one wave per output folds the RED_BLOCKS partials in a fixed order
 __global__ __launch_bounds__(64) void reduce_stage2(const double *__restrict__ partial,
                                                     int64_t nchains, double *__restrict__ out) {
-  const int q = blockIdx.x;  // 0 .. 2*NQ-1
+  const int q = blockIdx.x;  // 0 .. NP-1
   double t = 0;
-  for (int blk = threadIdx.x; blk < RED_BLOCKS; blk += 64) t += partial[blk * 2 * NQ + q];
+  for (int blk = threadIdx.x; blk < RED_BLOCKS; blk += 64) t += partial[blk * NP + q];
   t = wave_sum(t);
   if (threadIdx.x == 0) {
     out[1 + q] = t;
@@ -712,7 +729,7 @@ __global__ void reset_sampler_kernel(DevState S, double phi_step, double theta_s
 // by `lag` until the next accepted move -- reproduced here.
 template <typename R, typename G>
 __global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
-                              int chain_type, int energy_type, int force_init) {
+                              int chain_type, int energy_type, int force_init, int umbrella) {
   int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= S.C) return;
   const int64_t C = S.C, n = A.n;
@@ -753,8 +770,11 @@ __global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restri
     adopt = eps <= (exp(-(U_new - U_old) / cc.kT) * prod_new / prod_old);
   }
   if (adopt) {
-    const double lp_old = -U_old / cc.kT + log(prod_old);
-    const double lp_new = -U_new / cc.kT + log(prod_new);
+    // the cached log-density includes the umbrella weight function w = sum(u) * wscale (inc/acceptance.jl:13-16,
+    // inc/average.jl:104-124); wscale as in run_segment
+    const double ws = umbrella ? (0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT : 0.0;
+    const double lp_old = -U_old / cc.kT + log(prod_old) + S.obs[OBS_USUM * C + c] * ws;
+    const double lp_new = -U_new / cc.kT + log(prod_new) + usum * ws;
     S.lag[c] = (lp_old + S.lag[c]) - lp_new;
     for (int64_t i = 0; i < n; ++i) { th[i * C + c] = nth[i * C + c]; ph[i * C + c] = nph[i * C + c]; }
     S.obs[OBS_R1 * C + c] = r[0]; S.obs[OBS_R2 * C + c] = r[1]; S.obs[OBS_R3 * C + c] = r[2];
@@ -849,7 +869,7 @@ hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_
   return hipSuccess;
 }
 
-// queue layout: [0] job counter, [1] error flag, [2 ..] per-block "segments done"
+// queue layout: [0] error flag (sticky: never cleared by a launch), [1] job counter, [2 ..] per-block "segments done"
 size_t sweep_queue_ints(const SweepArgs &a) { return 2 + (size_t)(a.blocks_per_case * a.ncases); }
 
 hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
@@ -858,7 +878,7 @@ hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState
   const int lds = sweep_lds_bytes(cfg, a);
   hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(queue, 0, sizeof(int) * sweep_queue_ints(a), stream);
+  e = hipMemsetAsync(queue + 1, 0, sizeof(int) * (sweep_queue_ints(a) - 1), stream);
   if (e != hipSuccess) return e;
   SweepRare rare{cfg.do_flips, cfg.lag, cfg.umbrella};
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, stream, a, s, cases, rare, queue);
@@ -899,13 +919,13 @@ static void launch_reinit_g(const LaunchCfg &cfg, const SweepArgs &a, const DevS
                             int force_init, unsigned grid, hipStream_t stream) {
   if (cfg.precision == PSTAT_F64)
     hipLaunchKernelGGL((reinit_kernel<double, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
-                       cfg.chain_type, cfg.energy_type, force_init);
+                       cfg.chain_type, cfg.energy_type, force_init, cfg.umbrella);
   else if (cfg.precision == PSTAT_Q16)
     hipLaunchKernelGGL((reinit_kernel<uint16_t, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
-                       cfg.chain_type, cfg.energy_type, force_init);
+                       cfg.chain_type, cfg.energy_type, force_init, cfg.umbrella);
   else
     hipLaunchKernelGGL((reinit_kernel<float, G>), dim3(grid), dim3(256), 0, stream, a, s, cases,
-                       cfg.chain_type, cfg.energy_type, force_init);
+                       cfg.chain_type, cfg.energy_type, force_init, cfg.umbrella);
 }
 
 hipError_t launch_reinit(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
@@ -916,15 +936,17 @@ hipError_t launch_reinit(const LaunchCfg &cfg, const SweepArgs &a, const DevStat
   return hipGetLastError();
 }
 
-size_t reduce_scratch_doubles() { return (size_t)RED_BLOCKS * 2 * NQ; }
+size_t reduce_scratch_doubles() { return (size_t)RED_BLOCKS * NP; }
+static_assert(NQ == PSTAT_NQ && NX == PSTAT_NX && 1 + NP == PSTAT_NRED, "reduction layout of include/pstat.h");
 
 hipError_t launch_reduce(const DevState &s, int64_t c0, int64_t c1, int64_t steps_recorded,
-                         int umbrella, double *partial, double *out, hipStream_t stream) {
+                         int umbrella, const CaseConst *cases, int64_t chains_per_case, int64_t n,
+                         double *partial, double *out, hipStream_t stream) {
   hipLaunchKernelGGL(reduce_stage1, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, stream, s, c0, c1,
-                     steps_recorded, umbrella, partial);
+                     steps_recorded, umbrella, cases, chains_per_case, n, partial);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reduce_stage2, dim3(2 * NQ), dim3(64), 0, stream, partial, c1 - c0, out);
+  hipLaunchKernelGGL(reduce_stage2, dim3(NP), dim3(64), 0, stream, partial, c1 - c0, out);
   return hipGetLastError();
 }
 

@@ -98,6 +98,13 @@ class Ensemble:
         check(self._L.pstat_rolling(self._h, icase, avg.ctypes.data_as(dp), se.ctypes.data_as(dp)))
         return avg, se
 
+    def chain_means(self, icase: int = -1) -> np.ndarray:
+        """Per-chain running means, shape [NQ, chains]: what the device reduction folds (pstat_chain_means)."""
+        m = self.num_chains * (self.ncases if icase < 0 else 1)
+        out = np.zeros((_lib.NQ, m))
+        check(self._L.pstat_chain_means(self._h, icase, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def microstate(self, chain: int = 0) -> np.ndarray:
         out = np.zeros(7)
         check(self._L.pstat_microstate(self._h, chain, out.ctypes.data_as(C.POINTER(C.c_double))))

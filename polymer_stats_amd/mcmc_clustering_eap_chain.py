@@ -26,7 +26,7 @@ import numpy as np
 
 from . import _lib
 from .julia_fmt import jl_float, jl_row, jl_vector
-from .mcmc_eap_chain import Averager, ReferenceError_, _Pool, _log, get_avg
+from .mcmc_eap_chain import Averager, ReferenceError_, _Pool, _log, get_avg, resolve_seed
 
 ROLL_HEADER = "step,r1,r2,r3,r1sq,r2sq,r3sq,rsq,p1,p2,p3,p1sq,p2sq,p3sq,psq,U,Usq,Ealign,psi"   # :259
 
@@ -71,7 +71,9 @@ def build_parser() -> argparse.ArgumentParser:
     a("--profile", "-Z", dest="profile", action="store_true", help="profile the program")
     # --- ours
     a("--num-chains", dest="num-chains", type=int, default=4096, help="independent chains run at once on the GPU(s) and pooled")
-    a("--seed", dest="seed", type=int, default=0, help="seed of the per-chain counter-seeded generators")
+    a("--seed", dest="seed", type=int, default=None,
+      help="seed of the per-chain generators; default: fresh OS entropy per run, like the reference's unseeded RNG "
+           "(the seed drawn is echoed on stderr at --verbose >= 2)")
     a("--devices", dest="devices", type=str, default="0", help="comma-separated HIP device ordinals; chains are sharded over them")
     a("--rng", dest="rng", type=str, default="mwc64x", help="per-chain generator: mwc64x | xoshiro128++")
     a("--precision", dest="precision", type=str, default="f32", help="device arithmetic: f32 (f64 running sums) | f64")
@@ -119,6 +121,7 @@ def julia_vector(text: str) -> list[float]:
 
 
 def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int) -> _lib.Params:
+    resolve_seed(pargs)
     ct = {"dielectric": _lib.DIELECTRIC, "polar": _lib.POLAR}.get(pargs["chain-type"])
     if ct is None:
         raise ReferenceError_("chain-type is not understood.")                       # inc/eap_chain.jl:86
@@ -222,8 +225,6 @@ def run(pargs: dict):
     """The top level of mcmc_clustering_eap_chain.jl:354-387 -> (scalar_averagers, vector_averagers, ar)."""
     if pargs["numeric-type"] not in ("float64", "float128", "dec128", "big"):
         raise ReferenceError_(f"numeric-type '{pargs['numeric-type']}' not understood")    # :191
-    if pargs["numeric-type"] != "float64":
-        _log(pargs, 2, "Warning", "per-chain sums are kept in Float64 on the device")
     try:
         ladder = julia_vector(pargs["burn-schedule"])
     except (ValueError, SyntaxError):
@@ -239,6 +240,7 @@ def run(pargs: dict):
         for mult in ladder:                                             # :366-383
             _stage(pool, int(pargs["burn-in"]), pargs, pargs["kT"] * mult, write=False)
         s = _stage(pool, int(pargs["num-steps"]), pargs, pargs["kT"], write=True)   # :385-386
+        pool.report_failures(pargs, s)
     finally:
         pool.close()
     avg, se = np.array(s.avg), np.array(s.stderr)

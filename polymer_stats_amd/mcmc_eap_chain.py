@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import argparse
 import math
+import os
 import sys
 import time
 from dataclasses import dataclass
@@ -75,7 +76,9 @@ def build_parser() -> argparse.ArgumentParser:
     a("--profile", "-Z", dest="profile", action="store_true", help="profile the program")
     # --- ours
     a("--num-chains", dest="num-chains", type=int, default=4096, help="independent chains run at once on the GPU(s) and pooled")
-    a("--seed", dest="seed", type=int, default=0, help="seed of the per-chain counter-seeded generators")
+    a("--seed", dest="seed", type=int, default=None,
+      help="seed of the per-chain generators; default: fresh OS entropy per run, like the reference's unseeded RNG "
+           "(the seed drawn is echoed on stderr at --verbose >= 2)")
     a("--devices", dest="devices", type=str, default="0", help="comma-separated HIP device ordinals; chains are sharded over them")
     a("--burn-in", dest="burn-in", type=int, default=0,
       help="steps discarded before averaging, per rung of --burn-schedule (0 = the reference's behaviour: record from step 1)")
@@ -99,14 +102,36 @@ def default_pargs(**overrides) -> dict:
     return d
 
 
+def fresh_seed() -> int:
+    """A new 63-bit seed per call: OS entropy, mixed with the clock and the pid in case the pool is a stub.
+    The reference never seeds Julia's RNG, so repeated identical command lines give independent samples
+    (run/interacting-compare-with-clustering_2021-09-28.jl:26-27 launches each case 25 times and takes the
+    scatter as its error bar); the drop-in must do the same unless --seed is given."""
+    v = int.from_bytes(os.urandom(8), "little") ^ time.time_ns() ^ (os.getpid() << 40)
+    return v & 0x7FFFFFFFFFFFFFFF
+
+
+WIDE_TYPES = {"float128": "80-bit extended (numpy.longdouble)", "dec128": "80-bit extended (numpy.longdouble)",
+              "big": "80-bit extended (numpy.longdouble)"}
+
+
 def _log(pargs, level: int, tag: str, msg: str):
     # Logging to stderr gated by --verbose (mcmc_eap_chain.jl:157-165): 3 info, 2 warn, 1 error
     if pargs["verbose"] >= level:
         print(f"[ {tag}: {msg}", file=sys.stderr)
 
 
+def resolve_seed(pargs: dict) -> int:
+    """--seed as given, or (once per pargs) a fresh one, echoed on stderr at --verbose >= 2 so the run can be repeated."""
+    if pargs.get("seed") is None:
+        pargs["seed"] = fresh_seed()
+        _log(pargs, 2, "Info", f"seed: {pargs['seed']} (fresh entropy; pass --seed {pargs['seed']} to reproduce this run)")
+    return pargs["seed"]
+
+
 def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int) -> _lib.Params:
     """pargs -> pstat_params, with the reference's error() branches (inc/eap_chain.jl:81-105)."""
+    resolve_seed(pargs)
     ct = {"dielectric": _lib.DIELECTRIC, "polar": _lib.POLAR}.get(pargs["chain-type"])
     if ct is None:
         raise ReferenceError_("chain-type is not understood.")
@@ -151,6 +176,13 @@ class _Pool:
 
     def __init__(self, pargs: dict, factory=None):
         factory = factory or params_from_pargs
+        resolve_seed(pargs)      # before the shards are made: every device gets the same seed, disjoint chain ids
+        self.numeric_type = pargs.get("numeric-type", "float64")
+        if self.numeric_type != "float64":
+            # mcmc_eap_chain.jl:186-197 switches the averagers' accumulation type.  Here the per-chain sums are
+            # Float64 on the device (the reference's default); what the option changes is the merge over chains.
+            _log(pargs, 2, "Warning", f"--numeric-type {self.numeric_type}: per-chain sums are Float64 on the device; the "
+                                      f"merge over chains is carried out in {WIDE_TYPES[self.numeric_type]}")
         devices = [int(d) for d in str(pargs["devices"]).split(",") if d != ""]
         total = int(pargs["num-chains"])
         if total < 1:
@@ -202,7 +234,30 @@ class _Pool:
         red = np.zeros(_lib.NRED)
         for e in self.parts:
             red += e.reduce_host(-1)
-        return summary_from_reduction(red, self.steps)
+        s = summary_from_reduction(red, self.steps)
+        if self.numeric_type != "float64":
+            # --numeric-type: pooled mean and across-chain standard error re-done in the wide type from the per-chain
+            # means (the same quantities the device reduction folds in Float64)
+            m = np.concatenate([e.chain_means(-1) for e in self.parts], axis=1).astype(np.longdouble)
+            C = m.shape[1]
+            mean = m.sum(axis=1) / C
+            se = np.sqrt(((m - mean[:, None]) ** 2).sum(axis=1) / (C - 1) / C) if C > 1 else np.zeros_like(mean)
+            for q in range(_lib.NOBS):
+                s.avg[q], s.stderr[q] = float(mean[q]), float(se[q])
+            s.acceptance_ratio, s.ar_stderr = float(mean[16]), float(se[16])
+            for q in range(2):
+                s.extra_avg[q], s.extra_stderr[q] = float(mean[17 + q]), float(se[17 + q])
+        return s
+
+    def report_failures(self, pargs, s):
+        """stderr only (stdout stays the reference's lines): what the reference hides -- proposals it rejected because
+        their energy was NaN/Inf, and chains sitting in a 1/r^3 singularity (no excluded volume, inc/eap_chain.jl:200-207)."""
+        if s.nan_rejects:
+            _log(pargs, 2, "Warning", f"{s.nan_rejects} proposals had a non-finite energy and were rejected "
+                                      f"({s.nan_rejects / max(1.0, s.attempted_updates):.3g} of all attempts)")
+        if s.chains_collapsed:
+            _log(pargs, 2, "Warning", f"{s.chains_collapsed} of {s.num_chains} chains have collapsed "
+                                      f"(|U| > 1e6 n kT: monomers on top of each other)")
 
     def microstate(self):
         return self.parts[0].microstate(0)
@@ -218,9 +273,6 @@ def mcmc(nsteps: int, pargs: dict):
         raise ReferenceError_(f"'{pargs['acc']}' acceptance criteria has not yet been implemented.")  # :184
     if pargs["numeric-type"] not in ("float64", "float128", "dec128", "big"):
         raise ReferenceError_(f"numeric-type '{pargs['numeric-type']}' not understood")                # :195
-    if pargs["numeric-type"] != "float64":
-        _log(pargs, 2, "Warning", "per-chain sums are kept in Float64 on the device; "
-                                  f"'{pargs['numeric-type']}' only affects nothing here")
     if pargs["ensemble-type"] != "force":
         raise ReferenceError_("'end-to-end' ensemble is an experimental option of the reference; "
                               "it has no device implementation")
@@ -258,6 +310,7 @@ def mcmc(nsteps: int, pargs: dict):
         s = pool.summary()
         _log(pargs, 3, "Info", f"total time elapsed: {time.time() - start}")
         _log(pargs, 3, "Info", f"acceptance rate: {s.acceptance_ratio}")
+        pool.report_failures(pargs, s)
     finally:
         pool.close()
     avg, se = np.array(s.avg), np.array(s.stderr)

@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(ps):
     for n in names:
         assert hasattr(lib, n), f"libpstat.so does not export {n}"
     assert sorted(ps._lib.SYMBOLS) == names, "binding's symbol list is out of date"
-    assert lib.pstat_abi_version() == 4
+    assert lib.pstat_abi_version() == 5
 
 
 def test_struct_layout_matches_header(ps, tmp_path):

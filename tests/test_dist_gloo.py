@@ -20,7 +20,8 @@ NCHAINS, NSTEPS = 24, 3000
 def reduction_vector(sums, norm, nacc, steps, extra):
     # 16 observables, acceptance ratio, and the clustering main's two extras (zero in the first main)
     m = np.concatenate([sums / norm[:, None], (nacc / steps)[:, None], extra / norm[:, None]], axis=1)
-    return np.concatenate([[m.shape[0]], m.sum(0), (m ** 2).sum(0)])
+    # trailing two entries: non-finite-energy rejections and collapsed chains (additive counts; zero here)
+    return np.concatenate([[m.shape[0]], m.sum(0), (m ** 2).sum(0), [0.0, 0.0]])
 
 
 def job(ob, mode):
@@ -59,6 +60,7 @@ def test_two_rank_merge_equals_single_process(tmp_path, oracle, mode):
     sums, norm, nacc, extra = oracle.run_many(job(oracle, mode), 0, NCHAINS, nthreads=4, mode=mode, extras=True)
     single = reduction_vector(sums, norm, nacc, NSTEPS, extra)
     np.testing.assert_allclose(merged, single, rtol=1e-12)
+    assert merged.shape == (ps.NRED,)
     s = ps.summary_from_reduction(merged, NSTEPS)
     m = sums / norm[:, None]
     np.testing.assert_allclose(np.array(s.avg), m.mean(0), rtol=1e-12)

@@ -120,3 +120,46 @@ def test_cli_device_sharding_is_invisible(tmp_path):
     assert len(ra) == len(rb) == 3
     np.testing.assert_allclose([float(x) for x in rb[-1].split(",")], [float(x) for x in ra[-1].split(",")], rtol=1e-11, atol=1e-12)
     assert open(tmp_path / "a_trajectory.csv").read() == open(tmp_path / "b_trajectory.csv").read()   # chain 0 is chain 0
+
+
+def _run_main(host, argv):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert host.main(argv) == 0
+    return buf.getvalue()
+
+
+def test_default_seed_gives_independent_runs_and_explicit_seed_reproduces(tmp_path):
+    """Seed contract (reference: unseeded RNG; its sweeps repeat one command and use the scatter,
+    run/interacting-compare-with-clustering_2021-09-28.jl:26-27, run/K1_E0-kT-phase.jl:19,30)."""
+    from polymer_stats_amd import mcmc_eap_chain as host
+    from polymer_stats_amd import mcmc_clustering_eap_chain as chost
+    base = ["-n", "16", "-e", "1.0", "-F", "0.5", "-N", "2000", "-s", "0", "-v", "0", "--num-chains", "128"]
+    a = _run_main(host, base + ["--prefix", str(tmp_path / "a")])
+    b = _run_main(host, base + ["--prefix", str(tmp_path / "b")])
+    assert a.splitlines()[0].startswith("<r>") and a.splitlines()[0] != b.splitlines()[0]
+    c = _run_main(host, base + ["--seed", "11", "--prefix", str(tmp_path / "c")])
+    d = _run_main(host, base + ["--seed", "11", "--prefix", str(tmp_path / "d")])
+    assert c == d
+    cb = ["-n", "12", "-e", "1.0", "-F", "0.5", "-N", "1500", "--burn-in", "300", "-s", "0", "-v", "0", "--num-chains", "64"]
+    e = _run_main(chost, cb + ["--prefix", str(tmp_path / "e")])
+    f = _run_main(chost, cb + ["--prefix", str(tmp_path / "f")])
+    assert e.splitlines()[0] != f.splitlines()[0]
+    g = _run_main(chost, cb + ["--seed", "3", "--prefix", str(tmp_path / "g")])
+    h = _run_main(chost, cb + ["--seed", "3", "--prefix", str(tmp_path / "h")])
+    assert g == h
+
+
+def test_numeric_type_wide_merge_matches_float64_and_warns(tmp_path, capsys):
+    """--numeric-type (mcmc_eap_chain.jl:186-197): the merge over chains runs in the wide type; the result agrees with
+    the Float64 device reduction to rounding, and stderr says what was done."""
+    from polymer_stats_amd import mcmc_eap_chain as host
+    base = ["-n", "16", "-e", "1.0", "-F", "0.5", "-N", "3000", "-s", "0", "-v", "2", "--num-chains", "256", "--seed", "9"]
+    a = _run_main(host, base + ["--prefix", str(tmp_path / "a")])
+    capsys.readouterr()
+    b = _run_main(host, base + ["--numeric-type", "float128", "--prefix", str(tmp_path / "b")])
+    err = capsys.readouterr().err
+    assert "--numeric-type float128" in err and "Float64 on the device" in err
+    for la, lb in zip(a.splitlines(), b.splitlines()):
+        va, vb = (np.array(eval(l.split("=")[1]), dtype=float) for l in (la, lb))
+        np.testing.assert_allclose(vb, va, rtol=1e-12, atol=1e-13)

@@ -176,3 +176,32 @@ def test_cluster_output_shapes():
     np.testing.assert_allclose(mu, [[0.0, 0.0, 2.0]])           # n = z: mu = K1 E0 z
     mu = chost._dipoles(pa, np.array([0.0]), np.array([math.pi / 2]))
     np.testing.assert_allclose(mu, [[0.0, 0.0, 0.5]], atol=1e-15)   # n = x: mu = K2 E0 z
+
+
+# ------------------------------------------------------------------ seed contract
+def test_default_seed_is_fresh_entropy_and_echoed(capsys):
+    """The reference never seeds its RNG (its sweeps launch one command 25x and use the scatter,
+    run/interacting-compare-with-clustering_2021-09-28.jl:26-27): --seed defaults to fresh entropy, the seed drawn
+    is echoed on stderr at -v >= 2 and kept in pargs so that every shard of the run uses the same one."""
+    for mod in (host, chost):
+        assert mod.parse_args([])["seed"] is None
+        assert mod.parse_args(["--seed", "17"])["seed"] == 17
+    seeds = {host.fresh_seed() for _ in range(64)}
+    assert len(seeds) == 64 and all(0 <= s < 2 ** 63 for s in seeds)
+    pa = host.default_pargs(verbose=2)
+    s1 = host.resolve_seed(pa)
+    err = capsys.readouterr().err
+    assert f"seed: {s1}" in err and f"--seed {s1}" in err
+    assert host.resolve_seed(pa) == s1 and capsys.readouterr().err == ""     # drawn once per run
+    pb = host.default_pargs(verbose=1)
+    s2 = host.resolve_seed(pb)
+    assert s2 != s1 and capsys.readouterr().err == ""                        # quiet below -v 2
+    pc = host.default_pargs(seed=5)
+    assert host.resolve_seed(pc) == 5
+    # both mains' parameter builders resolve it (shards are built from one pargs => one seed)
+    p1 = host.params_from_pargs(pa, 4, 0, 0)
+    p2 = host.params_from_pargs(pa, 4, 4, 0)
+    assert p1.seed == p2.seed == s1
+    pk = chost.default_pargs()
+    q1 = chost.params_from_pargs(pk, 4, 0, 0)
+    assert q1.seed == pk["seed"] and pk["seed"] is not None and pk["seed"] != s1
