@@ -1,29 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the fixed-force MCMC hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (starts its own N rank processes when N > 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (also fine)
 
-Workload (BASELINE.json configs[1]): non-interacting dielectric chain, n = 100, E0 = 1, K1 = 1,
-K2 = 0, kT = 1, b = 1, one point of the Fz sweep per bench step, 65 536 chains per GPU, 1e5 MC steps
-per chain (6.55e9 attempted monomer updates per GPU per step).  Weak scaling: every rank runs its own
-65 536 chains (global chain ids rank*65536 ...), no data-path collective; the only exchange is one
-RCCL all-reduce of the 39-double reduction vector per step.
+Workload (BASELINE.json configs[1]): non-interacting dielectric chain, n = 100, E0 = 1, K1 = 1, K2 = 0, kT = 1,
+b = 1, one point of the Fz sweep per bench step, 65 536 chains per GPU, 1e5 MC steps per chain (6.55e9 attempted
+monomer updates per GPU per step).  Weak scaling: every rank runs its own 65 536 chains (global chain ids
+rank*65536 ...), no data-path collective; the only exchange is one RCCL all-reduce of the 41-double reduction
+vector per step.
 
-A bench "step" = advance every chain of one Fz point by --mc-steps Monte-Carlo steps (ONE launch of
-the sweep kernel) + the on-device reduction + the all-reduce.  Chain states are created (on the
-device) before the timed region, so inputs are resident in HBM when it starts.
+A bench "step" = advance every chain of one Fz point by --mc-steps Monte-Carlo steps (ONE launch of the sweep
+kernel) + the on-device reduction + the all-reduce.  Chain states are created (on the device) before the timed
+region, so inputs are resident in HBM when it starts.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (16 B per attempted update
-in f32: one (theta, phi) pair read and written; 32 B in f64 -- SURVEY.md 8(d)) x updates per launch /
-mean launch time measured with HIP events on the launch stream.  The path is bound by VALU issue,
-not by HBM (state lives in LDS/registers); the extra `valu` object prices it against that ceiling.
+The headline (`value`, `dtype`, `roofline`, `valu`, `lds`) is measured on the f64 kernel -- Float64 is the
+reference's arithmetic (inc/types.jl, inc/eap_chain.jl:12-36) and that kernel reproduces the CPU oracle bit for
+bit.  The f32 kernel (f32 state and transcendentals, f64 running sums; the survey-sanctioned fast path) is timed
+in the same run with the same K/W and reported in the sibling object `fast_path`.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (32 B per attempted update in f64: one
+(theta, phi) pair read and written; 16 B in f32 -- SURVEY.md 8(d)) x updates per launch / mean launch time
+measured with HIP events on the launch stream.  The path keeps its state on chip, so that figure is an
+EQUIVALENT rate; what bounds the kernel is VALU issue (`valu`), and `lds` is the third fraction SURVEY 8(d)
+asks for.  `traffic` / `valu.ops_per_update` come from the PMC passes in profiles/pmc_traffic.json and are used
+only if that file was collected on the kernel sources being benchmarked (sha256 stamp), else null / estimate.
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,9 +42,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FZ_SWEEP = [round(0.05 * i, 2) for i in range(21)] + [1.5 + 0.5 * i for i in range(8)]  # run/noninteracting-compare-*.jl:21
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz = 7.86e13 lane-ops/s
-VALU_OPS_PER_UPDATE = 220      # SURVEY.md 8(d) estimate; replaced by the PMC-measured count when profiles/ has one
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz = 7.86e13 f32 lane-ops/s (f64: half of it)
+LDS_PEAK_GBS = 256 * 256 * 2.4              # CUs x 256 B/clk (MI355X_MICROARCH.md, LDS) x GHz = 157 TB/s
+VALU_OPS_ESTIMATE = {"f32": 220, "f64": 590, "q16": 220}   # SURVEY.md 8(d) / DESIGN 3.1; replaced by the PMC count when valid
+STATE_BYTES = {"f32": 16, "f64": 32, "q16": 8}              # one state cell read + written per attempted update
+DTYPE = {"f32": "f32 state+transcendentals, f64 running sums", "f64": "f64",
+         "q16": "u16 lattice angles, f32 transcendentals, f64 running sums"}
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources and their build recipe: the stamp of profiles/pmc_traffic.json."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "polymer_stats_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "polymer_stats_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "polymer_stats_amd", "csrc", "Makefile"), os.path.join(ROOT, "include", "pstat.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def host_cores():
@@ -102,6 +129,33 @@ def parity_vs_cpu(ps, prec, n, chains, mc_steps, device, cpu_mean, cpu_se):
     return out
 
 
+def spawn_ranks(args) -> int:
+    """--gpus N > 1 from a bare shell (WORLD_SIZE unset): start N fresh rank processes, one per GPU, BEFORE this
+    process makes any GPU call (it never does: torch is not even imported here), relay rank 0's JSON line, and
+    fail if any rank fails.  The reference's analogue is `pmap` over worker processes
+    (run/interacting_dielectric_study.jl:37-47)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        return 1
+    lines = [l for l in out0.decode().splitlines() if l.startswith("{")]
+    if len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,7 +164,9 @@ def main():
     ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
     ap.add_argument("--mc-steps", type=int, default=100000, help="MC steps per chain per bench step")
     ap.add_argument("--n", type=int, default=100)
-    ap.add_argument("--precision", choices=["f32", "f64", "q16"], default="f32")
+    ap.add_argument("--precision", choices=["f64", "f32", "q16"], default="f64",
+                    help="arithmetic of the headline line (default f64 = the reference's Float64)")
+    ap.add_argument("--no-fast-path", action="store_true", help="skip the sibling f32 measurement")
     ap.add_argument("--rng", choices=["mwc64x", "xoshiro128++"], default="mwc64x",
                     help="per-chain generator (default MWC64X; xoshiro128++ is the north star's named one, measured slower here)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -118,6 +174,9 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend; gloo (via host memory) only to rehearse N>1 on a box with fewer GPUs")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     # Libraries (RCCL's version banner, HIP warnings) may write to stdout; the contract is ONE JSON
     # line there.  Park the real stdout and send everything else to stderr until the line is printed.
@@ -133,7 +192,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libpstat has no CPU path")
     ndev = torch.cuda.device_count()
@@ -160,117 +219,155 @@ def main():
             dist.all_reduce(host, **kw)
             tensor.copy_(host)
 
-    prec = {"f32": ps.F32, "f64": ps.F64, "q16": ps.Q16}[args.precision]
+    PREC = {"f32": ps.F32, "f64": ps.F64, "q16": ps.Q16}
     stream = torch.cuda.Stream()
     nstep_total = args.steps + args.warmup
     red = torch.zeros(ps.NRED, dtype=torch.float64, device="cuda")
-    with torch.cuda.stream(stream):
-        # one ensemble per bench step (a point of the Fz sweep), initialised on the device up front
-        ens = []
-        for i in range(nstep_total):
-            p = ps.default_params(n=args.n, E0=1.0, K1=1.0, K2=0.0, kT=1.0, b=1.0, Fz=FZ_SWEEP[i % len(FZ_SWEEP)],
-                                  num_chains=args.chains, chain_id0=rank * args.chains,
-                                  seed=20260501 + i, precision=prec, device=local_rank,
-                                  rng=ps.RNG_XOSHIRO128PP if args.rng == "xoshiro128++" else ps.RNG_MWC64X)
-            ens.append(ps.Ensemble(p, stream=stream.cuda_stream))
-        info = ens[0].launch_info()
-        log(f"rank {rank}: {nstep_total} ensembles ready; kernel {info.kernel.decode()} lds={info.lds_bytes} "
-            f"wgs={info.blocks} wg/cu={info.blocks_per_cu}")
 
-        def one_step(e, ev=None):
-            if ev:
-                ev[0].record(stream)
-            e.advance(args.mc_steps)
-            if ev:
-                ev[1].record(stream)
-            e.reduce_into(red.data_ptr())
-            if use_dist:
-                all_reduce(red)
+    def measure(precision: str):
+        """W warm-up + K timed bench steps of the sweep kernel in `precision`; returns the timing record."""
+        prec = PREC[precision]
+        with torch.cuda.stream(stream):
+            # one ensemble per bench step (a point of the Fz sweep), initialised on the device up front
+            ens = []
+            for i in range(nstep_total):
+                p = ps.default_params(n=args.n, E0=1.0, K1=1.0, K2=0.0, kT=1.0, b=1.0, Fz=FZ_SWEEP[i % len(FZ_SWEEP)],
+                                      num_chains=args.chains, chain_id0=rank * args.chains,
+                                      seed=20260501 + i, precision=prec, device=local_rank,
+                                      rng=ps.RNG_XOSHIRO128PP if args.rng == "xoshiro128++" else ps.RNG_MWC64X)
+                ens.append(ps.Ensemble(p, stream=stream.cuda_stream))
+            info = ens[0].launch_info()
+            log(f"rank {rank}: {precision}: {nstep_total} ensembles ready; kernel {info.kernel.decode()} "
+                f"lds={info.lds_bytes} lanes={info.lanes_per_block} wgs={info.blocks} wg/cu={info.blocks_per_cu}")
 
-        for i in range(args.warmup):
-            tw = time.perf_counter()
-            one_step(ens[i])
+            def one_step(e, ev=None):
+                if ev:
+                    ev[0].record(stream)
+                e.advance(args.mc_steps)
+                if ev:
+                    ev[1].record(stream)
+                e.reduce_into(red.data_ptr())
+                if use_dist:
+                    all_reduce(red)
+
+            for i in range(args.warmup):
+                tw = time.perf_counter()
+                one_step(ens[i])
+                torch.cuda.synchronize()
+                log(f"rank {rank}: {precision}: warmup step {i} took {time.perf_counter() - tw:.3f} s")
             torch.cuda.synchronize()
-            log(f"rank {rank}: warmup step {i} took {time.perf_counter() - tw:.3f} s")
-        torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                      for _ in range(args.steps)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                one_step(ens[args.warmup + i], events[i])
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            log(f"rank {rank}: {precision}: {args.steps} timed steps in {elapsed:.3f} s")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         if use_dist:
-            dist.barrier()
-        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                  for _ in range(args.steps)]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            one_step(ens[args.warmup + i], events[i])
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        log(f"rank {rank}: {args.steps} timed steps in {elapsed:.3f} s")
+            all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        kernel_ms = [a.elapsed_time(b) for a, b in events]
+        ens[-1].sync()           # surfaces a timed-out persistent launch (PSTAT_ERR_HIP) instead of timing garbage
+        last = ps.summary_from_reduction(red.cpu().tolist(), args.mc_steps)
+        for e in ens:
+            e.close()
+        return dict(precision=precision, elapsed=elapsed, kernel_ms=kernel_ms, last=last, info=info)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if use_dist:
-        all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in events]
-    last = ps.summary_from_reduction(red.cpu().tolist(), args.mc_steps)
+    def price(rec, pmc):
+        """value / roofline / valu / lds of one timing record."""
+        precision = rec["precision"]
+        upd_per_launch = args.chains * args.mc_steps
+        mean_ms = sum(rec["kernel_ms"]) / len(rec["kernel_ms"])
+        rate = upd_per_launch / (mean_ms * 1e-3)             # updates/s of the kernel alone
+        achieved = STATE_BYTES[precision] * rate / 1e9
+        key = f"{precision}_n{args.n}_c{args.chains}_s{args.mc_steps}"
+        traffic, valu_ops, src = None, VALU_OPS_ESTIMATE[precision], "estimate (no PMC record for these kernel sources)"
+        if pmc and key in pmc.get("records", {}):
+            r = pmc["records"][key]
+            traffic = r.get("hbm_bytes_per_launch")
+            if r.get("valu_instructions_per_update_per_lane"):
+                valu_ops = r["valu_instructions_per_update_per_lane"]
+                src = "SQ_INSTS_VALU x 64 / updates, profiles/pmc_traffic.json (stamp = sha256 of the kernel sources)"
+        valu_peak = VALU_LANE_OPS_PEAK * (0.5 if precision == "f64" else 1.0)   # v_fma_f64: 16 lanes/clk/SIMD
+        last, info = rec["last"], rec["info"]
+        return {
+            "value": world * upd_per_launch * args.steps / rec["elapsed"],
+            "ms_per_step": rec["elapsed"] / args.steps * 1e3,
+            "dtype": DTYPE[precision],
+            "kernel": info.kernel.decode(), "lds_bytes_per_wg": info.lds_bytes, "lanes_per_wg": info.lanes_per_block,
+            "workgroups": int(info.blocks), "wg_per_cu_resident": info.blocks_per_cu,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": mean_ms,
+                         "equivalent": True,
+                         "note": "algorithmic bytes = %d B/update x %d updates per launch / HIP-event kernel time; state is "
+                                 "on-chip resident, so this is an equivalent rate, not HBM traffic (see `traffic`); the "
+                                 "kernel's real bound is `valu`" % (STATE_BYTES[precision], upd_per_launch)},
+            "valu": {"bound": "valu-issue", "achieved": rate * valu_ops / 1e12, "peak": valu_peak / 1e12,
+                     "unit": "T lane-ops/s", "frac": rate * valu_ops / valu_peak,
+                     "ops_per_update": valu_ops, "ops_source": src},
+            "lds": {"bound": "lds-bandwidth", "achieved": STATE_BYTES[precision] * rate / 1e9, "peak": LDS_PEAK_GBS,
+                    "unit": "GB/s", "frac": STATE_BYTES[precision] * rate / 1e9 / LDS_PEAK_GBS,
+                    "note": "one state cell read + one written per update (ds_read/ds_write of %d B)" % (STATE_BYTES[precision] // 2)},
+            "check": {"Fz": FZ_SWEEP[(nstep_total - 1) % len(FZ_SWEEP)], "r3": last.avg[2], "r3_stderr": last.stderr[2],
+                      "p3": last.avg[9], "U": last.avg[14], "AR": last.acceptance_ratio,
+                      "chains_pooled": int(last.num_chains), "nan_rejects": int(last.nan_rejects),
+                      "chains_collapsed": int(last.chains_collapsed)},
+        }
+
+    head = measure(args.precision)
+    fast = None
+    if args.precision == "f64" and not args.no_fast_path:
+        fast = measure("f32")
 
     if rank == 0:
-        upd_per_launch = args.chains * args.mc_steps
-        total_updates = world * upd_per_launch * args.steps
-        value = total_updates / elapsed
-        mean_ms = sum(kernel_ms) / len(kernel_ms)
-        bytes_per_update = {ps.F32: 16, ps.F64: 32, ps.Q16: 8}[prec]   # one state cell read + written
-        achieved = bytes_per_update * upd_per_launch / (mean_ms * 1e-3) / 1e9
-        traffic, valu_ops, valu_src = None, VALU_OPS_PER_UPDATE, "SURVEY.md 8(d) estimate"
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                key = f"{args.precision}_n{args.n}_c{args.chains}_s{args.mc_steps}"
-                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
-                if rec.get(key, {}).get("valu_instructions_per_update_per_lane"):
-                    valu_ops = rec[key]["valu_instructions_per_update_per_lane"]
-                    valu_src = "SQ_INSTS_VALU x 64 / updates, profiles/pmc_traffic.json"
-            except Exception:
-                traffic = None
-        upd_rate_kernel = upd_per_launch / (mean_ms * 1e-3)
+        pmc = None
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if rec.get("kernel_source_sha256_16") == kernel_source_hash():
+                pmc = rec
+            else:
+                log("profiles/pmc_traffic.json was collected on other kernel sources: traffic = null, VALU count = estimate")
+        except Exception:
+            pass
+        h = price(head, pmc)
         out = {
             "metric": "MC monomer-updates/sec (whole node) at n=100",
-            "value": value, "unit": "MC monomer-updates/s",
+            "value": h["value"], "unit": "MC monomer-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": h["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {ps.F32: "f32 state+transcendentals, f64 running sums", ps.F64: "f64",
-                      ps.Q16: "u16 lattice angles, f32 transcendentals, f64 running sums"}[prec],
-            "data": "synthetic",
+            "dtype": h["dtype"], "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: non-interacting dielectric chain, n=%d, E0=1, K1=1, K2=0, "
                                    "kT=1, b=1, Fz sweep (one point per step), %d chains/GPU x %d MC steps"
                                    % (args.n, args.chains, args.mc_steps),
                        "chains_per_gpu": args.chains, "mc_steps_per_chain": args.mc_steps, "n": args.n,
                        "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-reduce of {ps.NRED} doubles per step",
-                       "kernel": info.kernel.decode(), "rng": args.rng, "lds_bytes_per_wg": info.lds_bytes,
-                       "workgroups": int(info.blocks), "wg_per_cu_resident": info.blocks_per_cu},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": mean_ms,
-                         "note": "algorithmic bytes = %d B/update x %d updates per launch; the kernel keeps state in "
-                                 "LDS/registers, so HBM is not what bounds it -- see 'valu'" % (bytes_per_update, upd_per_launch)},
-            "valu": {"bound": "valu-issue", "achieved": upd_rate_kernel * valu_ops / 1e12,
-                     "peak": VALU_LANE_OPS_PEAK / 1e12, "unit": "T lane-ops/s",
-                     "frac": upd_rate_kernel * valu_ops / VALU_LANE_OPS_PEAK,
-                     "ops_per_update": valu_ops, "ops_source": valu_src},
-            "check": {"Fz": FZ_SWEEP[(nstep_total - 1) % len(FZ_SWEEP)], "r3": last.avg[2], "r3_stderr": last.stderr[2],
-                      "p3": last.avg[9], "U": last.avg[14], "AR": last.acceptance_ratio,
-                      "chains_pooled": int(last.num_chains)},
+                       "kernel": h["kernel"], "rng": args.rng, "lds_bytes_per_wg": h["lds_bytes_per_wg"],
+                       "lanes_per_wg": h["lanes_per_wg"], "workgroups": h["workgroups"],
+                       "wg_per_cu_resident": h["wg_per_cu_resident"]},
+            "roofline": h["roofline"], "valu": h["valu"], "lds": h["lds"], "check": h["check"],
         }
+        if fast is not None:
+            f = price(fast, pmc)
+            out["fast_path"] = {k: f[k] for k in ("value", "ms_per_step", "dtype", "kernel", "lanes_per_wg",
+                                                  "wg_per_cu_resident", "roofline", "valu", "lds", "check")}
+            out["fast_path"]["bias_bound"] = ("<= 5e-6 relative on every pooled average against the closed form "
+                                              "(profiles/r01_final/bias_f32_long.json; DESIGN.md section 5)")
         if world == 1 and not args.no_cpu_baseline:
             base, cpu_mean, cpu_se = cpu_baseline(args.n, args.mc_steps)
-            base["parity"] = parity_vs_cpu(ps, prec, args.n, args.chains, args.mc_steps, local_rank, cpu_mean, cpu_se)
+            base["parity"] = parity_vs_cpu(ps, PREC[args.precision], args.n, args.chains, args.mc_steps, local_rank, cpu_mean, cpu_se)
+            if fast is not None:
+                base["parity_fast_path"] = parity_vs_cpu(ps, ps.F32, args.n, args.chains, args.mc_steps, local_rank, cpu_mean, cpu_se)
             out["cpu_baseline"] = base
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    for e in ens:
-        e.close()
     if use_dist:
         dist.destroy_process_group()
 

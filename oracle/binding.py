@@ -44,7 +44,7 @@ class EapResult(C.Structure):
                 ("nacc_total", C.c_int64), ("nsteps_total", C.c_int64),
                 ("phi_step", C.c_double), ("theta_step", C.c_double),
                 ("r", C.c_double * 3), ("p", C.c_double * 3), ("U", C.c_double),
-                ("rng", C.c_uint32 * 4), ("extra_sum", C.c_double * 2)]
+                ("rng", C.c_uint32 * 4), ("extra_sum", C.c_double * 2), ("nan_rejects", C.c_int64)]
 
 
 class EapTrace(C.Structure):
@@ -143,6 +143,7 @@ class Run:
     rolling: np.ndarray | None = None
     traj: np.ndarray | None = None
     extra_sums: np.ndarray | None = None      # clustering main: sum cos^2(theta), mean psi
+    nan_rejects: int = 0                      # proposals with a non-finite trial energy
     extra: dict = field(default_factory=dict)
 
     @property
@@ -158,7 +159,7 @@ def _unpack(res: EapResult) -> Run:
     return Run(sums=np.array(res.sum[:]), norm=res.norm, nacc_total=res.nacc_total,
                nsteps_total=res.nsteps_total, phi_step=res.phi_step, theta_step=res.theta_step,
                r=np.array(res.r[:]), p=np.array(res.p[:]), U=res.U, rng=np.array(res.rng[:], dtype=np.uint32),
-               extra_sums=np.array(res.extra_sum[:]))
+               extra_sums=np.array(res.extra_sum[:]), nan_rejects=int(res.nan_rejects))
 
 
 def run(params: EapParams, chain_id: int = 0, mode: str = "faithful", trace: bool = False,

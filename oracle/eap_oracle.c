@@ -446,7 +446,7 @@ int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, ea
 
   averagers_t A;
   memset(&A, 0, sizeof A);
-  int64_t nacc = 0, nacc_total = 0, natt = 0;
+  int64_t nacc = 0, nacc_total = 0, natt = 0, nan_rejects = 0;
   int64_t t = 0;
 
   for (int64_t init = 1; init <= P->num_inits; ++init) {        /* :266 */
@@ -463,6 +463,7 @@ int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, ea
       /* Metropolis functor, acceptance.jl:29-39 */
       double logpi = -trial.U / P->kT + trial.Omega + (wf.on ? weight_eval(&wf, sum_us(&trial)) : 1.0);
       int ok = (logpi >= logpi_prev) || (eps < exp(logpi - logpi_prev));
+      if (!isfinite(trial.U)) ++nan_rejects;
       if (ok) {
         logpi_prev = logpi;
         chain_t tmp = cur; cur = trial; trial = tmp;            /* :288 */
@@ -495,6 +496,7 @@ int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, ea
   out->norm = A.norm;
   out->extra_sum[0] = out->extra_sum[1] = 0.0;
   out->nacc_total = nacc_total;
+  out->nan_rejects = nan_rejects;
   out->nsteps_total = P->num_inits * P->num_steps;
   out->phi_step = phistep;
   out->theta_step = thstep;
@@ -561,7 +563,8 @@ static void record_extra(double ex[2], const chain_t *c, int umbrella, double w)
 /* one call of mcmc(nsteps, pargs, chain), mcmc_clustering_eap_chain.jl:172-352 */
 static void cluster_stage(const eap_params *P, int64_t nsteps, uint32_t rng[5], chain_t *cur, chain_t *trial,
                           averagers_t *A, double extra[2], int64_t *nacc_total_out, double steps_out[2],
-                          eap_trace *tr, int64_t *t) {
+                          eap_trace *tr, int64_t *t, int64_t *nan_rejects) {
+  *nan_rejects = 0;
   double phistep = P->phi_step, thstep = P->theta_step;           /* :174 */
   cur->U = chain_U(P, cur);                                       /* :177 */
   weight_t wf = weight_make(P, cur->Omega);                       /* :178 */
@@ -580,6 +583,7 @@ static void cluster_stage(const eap_params *P, int64_t nsteps, uint32_t rng[5], 
     /* acceptance.jl:29-39 with alpha; the cached value keeps the log(alpha) of the accepted move */
     double logpi = -trial->U / P->kT + trial->Omega + (wf.on ? weight_eval(&wf, sum_us(trial)) : 1.0) + log(alpha);
     int ok = (logpi >= logpi_prev) || (eps < exp(logpi - logpi_prev));
+    if (!isfinite(trial->U)) ++*nan_rejects;
     if (ok) {
       logpi_prev = logpi;
       chain_t tmp = *cur; *cur = *trial; *trial = tmp;
@@ -610,22 +614,23 @@ int eap_run_cluster(const eap_params *P0, uint64_t chain_id, eap_result *out, ea
   eap_params P = *P0;
   averagers_t A;
   double extra[2], steps[2] = {P0->phi_step, P0->theta_step};
-  int64_t nacc_total = 0, t = 0;
+  int64_t nacc_total = 0, t = 0, nan_rejects = 0;
   chain_random(&P, rng, &cur);                                    /* mcmc(nsteps, pargs): EAPChain(pargs), :167-170 */
   /* burn-in ladder, :365-386: every rung is a fresh mcmc() call (fresh acceptor, averagers, step sizes) */
   for (int s = 0; s < P0->burn_nsched; ++s) {
     P.kT = P0->kT * P0->burn_sched[s];
     if (tr) tr->rows_written = 0;                                 /* each call rewrites the CSV files */
-    cluster_stage(&P, P0->burn_in, rng, &cur, &trial, &A, extra, &nacc_total, steps, tr, &t);
+    cluster_stage(&P, P0->burn_in, rng, &cur, &trial, &A, extra, &nacc_total, steps, tr, &t, &nan_rejects);
   }
   P.kT = P0->kT;
   if (tr) tr->rows_written = 0;
-  cluster_stage(&P, P0->num_steps, rng, &cur, &trial, &A, extra, &nacc_total, steps, tr, &t);
+  cluster_stage(&P, P0->num_steps, rng, &cur, &trial, &A, extra, &nacc_total, steps, tr, &t, &nan_rejects);
 
   memcpy(out->sum, A.sum, sizeof A.sum);
   out->norm = A.norm;
   out->extra_sum[0] = extra[0]; out->extra_sum[1] = extra[1];
   out->nacc_total = nacc_total;
+  out->nan_rejects = nan_rejects;
   out->nsteps_total = P0->num_steps;
   out->phi_step = steps[0]; out->theta_step = steps[1];
   memcpy(out->r, cur.r, sizeof cur.r);
@@ -741,7 +746,7 @@ int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_tr
 
   averagers_t A;
   memset(&A, 0, sizeof A);
-  int64_t nacc = 0, nacc_total = 0, natt = 0, t = 0;
+  int64_t nacc = 0, nacc_total = 0, natt = 0, t = 0, nan_rejects = 0;
 
   for (int64_t init = 1; init <= P->num_inits; ++init) {
     for (int64_t step = 1; step <= P->num_steps; ++step, ++t) {
@@ -776,6 +781,7 @@ int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_tr
       double dw = wf.on ? du * wf.scale : 0.0;
       double delta = -dU / P->kT + log(st / c.sth[idx]) + dw - lag;
       int ok = (delta >= 0.0) || (eps < exp(delta));
+      if (!isfinite(dU)) ++nan_rejects;
       if (ok) {
         c.phi[idx] = phi1; c.th[idx] = th1; c.sth[idx] = st;
         for (int k = 0; k < 3; ++k) {
@@ -820,6 +826,7 @@ int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_tr
   out->norm = A.norm;
   out->extra_sum[0] = out->extra_sum[1] = 0.0;
   out->nacc_total = nacc_total;
+  out->nan_rejects = nan_rejects;
   out->nsteps_total = P->num_inits * P->num_steps;
   out->phi_step = phistep; out->theta_step = thstep;
   memcpy(out->r, c.r, sizeof c.r); memcpy(out->p, c.p, sizeof c.p);

@@ -77,6 +77,8 @@ typedef struct eap_result {
   uint32_t rng[4];        /* final generator state                          */
   double extra_sum[2];    /* clustering main only: sum cos^2(theta_i) and mean bond angle psi
                              (mcmc_clustering_eap_chain.jl:243-244) */
+  int64_t nan_rejects;    /* proposals whose trial energy was NaN or +-Inf: the reference rejects them
+                             silently (every comparison in inc/acceptance.jl:29-39 is false) */
 } eap_result;
 
 /* Optional per-run outputs; any pointer may be NULL. */

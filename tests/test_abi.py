@@ -41,14 +41,15 @@ def test_struct_layout_matches_header(ps, tmp_path):
                    'offsetof(pstat_summary, num_chains), sizeof(pstat_launch_info));'
                    'printf("%zu %zu %zu %zu\\n", offsetof(pstat_params, move_set), offsetof(pstat_params, bend_mod),'
                    'offsetof(pstat_params, use_x0), offsetof(pstat_summary, extra_avg));'
-                   'printf("%zu\\n", offsetof(pstat_params, cutoff_radius));return 0;}\n')
+                   'printf("%zu %zu %d %d\\n", offsetof(pstat_params, cutoff_radius), offsetof(pstat_summary, nan_rejects),'
+                   'PSTAT_NRED, PSTAT_NQ);return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     P, S, LI = ps._lib.Params, ps._lib.Summary, ps._lib.LaunchInfo
     assert got == [C.sizeof(P), P.steps_per_adjust.offset, P.seed.offset, P.rng.offset, C.sizeof(S),
                    S.num_chains.offset, C.sizeof(LI), P.move_set.offset, P.bend_mod.offset, P.use_x0.offset,
-                   S.extra_avg.offset, P.cutoff_radius.offset]
+                   S.extra_avg.offset, P.cutoff_radius.offset, S.nan_rejects.offset, ps.NRED, ps.NQ]
 
 
 def test_defaults_are_the_references(ps):

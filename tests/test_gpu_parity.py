@@ -28,6 +28,7 @@ def _bit_parity(ps, oracle, nsteps, nchains, **kw):
     with ps.Ensemble(pp) as e:
         e.advance(nsteps)
         e.sync()
+        nan_oracle = 0
         for c in range(nchains):
             o = oracle.run(op, chain_id=c, mode="fast", trace=True)
             g = e.chain_state(c)
@@ -38,6 +39,8 @@ def _bit_parity(ps, oracle, nsteps, nchains, **kw):
             assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step
             np.testing.assert_allclose(g["sums"], o.sums, rtol=1e-9, atol=1e-7)
             np.testing.assert_allclose(e.microstate(c), np.r_[o.r, o.p, o.U], rtol=1e-9, atol=1e-9)
+            nan_oracle += o.nan_rejects
+        assert e.summary().nan_rejects == nan_oracle      # proposals with a non-finite trial energy: same count
 
 
 @pytest.mark.parametrize("rng", [0, 1])
@@ -49,13 +52,18 @@ def test_f64_bit_parity_config1(ps, oracle, rng):
 def test_f64_bit_parity_dielectric_fx_flips(ps, oracle):
     _bit_parity(ps, oracle, 6000, 64, n=33, E0=1.5, K1=0.7, K2=0.3, Fz=0.4, Fx=0.3, kT=0.7, b=1.3,
                 do_flips=1, seed=5, steps_per_adjust=500, rng=1)
-    # sharded ids far apart: the skip-ahead seeding must agree for large chain ids too
-    op, pp = both(800, num_chains=64, precision=ps.F64, chain_id0=(1 << 33) + 5, n=10, E0=1.0, Fz=0.5, seed=5)
-    with ps.Ensemble(pp) as e:
-        e.advance(800)
-        o = oracle.run(op, chain_id=(1 << 33) + 5 + 63, mode="fast", trace=True)
-        g = e.chain_state(63)
-        assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["rng"], o.rng)
+    # sharded ids far apart: the seeding must agree for large chain ids too -- MWC64X (skip-ahead) up to its
+    # disjointness bound of 2^22 ids, xoshiro128++ (Philox-seeded) for any 64-bit id
+    for rng, id0 in ((0, (1 << 22) - 64), (1, (1 << 33) + 5)):
+        op, pp = both(800, num_chains=64, precision=ps.F64, chain_id0=id0, n=10, E0=1.0, Fz=0.5, seed=5, rng=rng)
+        with ps.Ensemble(pp) as e:
+            e.advance(800)
+            o = oracle.run(op, chain_id=id0 + 63, mode="fast", trace=True)
+            g = e.chain_state(63)
+            assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["rng"], o.rng)
+    # beyond the bound the MWC64X streams would wrap onto each other: refused, not silently accepted
+    with pytest.raises(ps.PstatError, match="MWC64X streams are disjoint only"):
+        ps.Ensemble(ps.default_params(num_chains=64, chain_id0=(1 << 22) - 63, n=10))
 
 
 def test_f64_bit_parity_polar(ps, oracle):
@@ -493,8 +501,10 @@ def test_f64_bit_parity_random_configurations(ps, oracle):
         nsteps = 400 if et == 1 else 1200
         inits = int(rng.choice([1, 1, 2]))
         force = int(rng.integers(0, 2))
-        op, pp = both(nsteps, num_chains=3, precision=ps.F64, num_inits=inits, force_init=force,
-                      chain_id0=int(rng.integers(0, 2 ** 33)), **kw)
+        cid = int(rng.integers(0, 2 ** 33))
+        if kw["rng"] == 0:
+            cid %= (1 << 22) - 3      # MWC64X: ids below its stream-disjointness bound
+        op, pp = both(nsteps, num_chains=3, precision=ps.F64, num_inits=inits, force_init=force, chain_id0=cid, **kw)
         with ps.Ensemble(pp) as e:
             for k in range(inits):
                 e.advance(nsteps)

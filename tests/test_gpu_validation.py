@@ -1,0 +1,166 @@
+"""Round-2 parity cases on the GPU (all through the C ABI):
+  * every committed closed-form fixture (tests/golden/ni_closed_form.json) against the f32, q16 and f64 kernels,
+    sharply (burn-in, then the pooled averages must sit on the closed form within their own standard error):
+    BASELINE configs[1] at Fz = 0, 1, 5, configs[2] at E0 = 1 and 10, Fx != 0, K2 != 0;
+  * the reference's own validation workflow: E0 = 0 against the Langevin law over the force range of
+    run/prelim/test_noE.jl:18-21 (Fz up to 100), with that script's adaptation band (:38);
+  * the f32 all-pairs kernels at the reference's sweep sizes -- n = 64 (one monomer per lane), n = 100 (two,
+    packed ring sum), n = 200 (four) -- against the oracle's literal O(n^2) mode and against the f64 kernel;
+  * BASELINE configs[3] exactly as stated, f32 against f64;
+  * the failure counters of ABI v5.
+"""
+import numpy as np
+import pytest
+
+from helpers import both, pooled
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ps():
+    import polymer_stats_amd as ps
+    assert ps._lib.load().pstat_device_count() >= 1, "no HIP device visible"
+    return ps
+
+
+def _golden_params(ps, case):
+    P = case["params"]
+    return dict(n=int(P["n"]), E0=P["E0"], K1=P["K1"], K2=P["K2"], mu=P["mu"], kT=P["kT"], Fz=P["Fz"], Fx=P["Fx"], b=P["b"],
+                chain_type=ps.POLAR if P["chain"] == "polar" else ps.DIELECTRIC)
+
+
+GOLDEN_N100 = ["cfg2_n100_E0_1_K1_1_Fz0", "cfg2_n100_E0_1_K1_1_Fz1", "cfg2_n100_E0_1_K1_1_Fz5",
+               "cfg3_polar_n100_E0_10_mu1_Fz025", "cfg3_polar_n100_E0_1_mu1_Fz1", "diel_n100_E0_1_K1_1_Fx1",
+               "diel_n100_E0_2_K2_1_Fz05"]
+
+
+@pytest.mark.parametrize("prec", [0, 2, 1], ids=["f32", "q16", "f64"])
+@pytest.mark.parametrize("name", GOLDEN_N100 + ["cfg1_n20_E0_0_Fz1", "diel_n8_E0_15_K1_07_K2_03_Fz04_Fx03_kT07_b13"])
+def test_every_closed_form_fixture_sharply(ps, golden, name, prec):
+    """All 16 pooled averages within 5 of THEIR OWN standard errors of the closed form (no transient: hot rung, target
+    temperature, reset, record).  65 536 chains x 5e4 recorded steps resolve <r_z> to ~1e-4 relative."""
+    kw = _golden_params(ps, golden[name])
+    nch = 8192 if prec == 1 else 65536
+    pp = ps.default_params(num_chains=nch, precision=prec, seed=20260502, **kw)
+    with ps.Ensemble(pp) as e:
+        e.set_kT(3.0 * kw["kT"])
+        e.advance(10000)
+        e.set_kT(kw["kT"])
+        e.advance(30000)
+        e.reset_averages()
+        e.advance(50000)
+        s = e.summary()
+    avg, se = np.array(s.avg), np.array(s.stderr)
+    eq = golden[name]["avg"]
+    z = np.array([(avg[k] - eq[nm]) / (se[k] + 1e-12 * (1 + abs(eq[nm]))) for k, nm in enumerate(ps.OBS_NAMES)])
+    assert np.all(np.abs(z) < 5.0), dict(zip(ps.OBS_NAMES, np.round(z, 2)))
+    assert s.nan_rejects == 0 and s.chains_collapsed == 0
+
+
+def _langevin(x):
+    return 1.0 / np.tanh(x) - 1.0 / x
+
+
+@pytest.mark.parametrize("prec", [0, 2, 1], ids=["f32", "q16", "f64"])
+def test_reference_validation_sweep_against_langevin(ps, prec):
+    """run/prelim/test_noE.jl:18-21,38: E0 = 0, n = 100, kT = b = 1, Fz from 0.05 to 100, adaptation band
+    [0.19, 0.39], checked against <r_z> = n b L(F b / kT), <r_z^2> and <U> = -F <r_z> (inc/langevin.jl is the
+    inverse of the same law).  The whole sweep is ONE batched launch (cases differ in Fz only).  Large forces
+    are where f32 differs from f64 most: exp2 range, step sizes adapted far down, theta pinned near 0."""
+    Fzs = [0.05, 0.5, 1.0, 2.0, 10.0, 40.0, 100.0]
+    nch = 2048 if prec == 1 else 16384
+    cases = [ps.default_params(num_chains=nch, precision=prec, n=100, E0=0.0, K1=1.0, K2=0.0, kT=1.0, b=1.0, Fz=F,
+                               adj_lb=0.19, adj_ub=0.39, adj_scale=1.1, seed=20260503) for F in Fzs]
+    with ps.Ensemble(cases) as e:
+        e.advance(60000)          # adaptation needs ~20 windows of 2500 steps to bring the steps down at F = 100
+        e.reset_averages()
+        e.advance(60000)
+        for i, F in enumerate(Fzs):
+            s = e.summary(i)
+            L = _langevin(F)
+            rz = 100.0 * L
+            var1 = 1.0 - 2.0 * L / F - L * L                 # Var(cos theta) of one monomer
+            rz2 = 100.0 * var1 + rz * rz
+            z = [(s.avg[2] - rz) / s.stderr[2], (s.avg[5] - rz2) / s.stderr[5], (s.avg[14] + F * rz) / s.stderr[14]]
+            assert np.all(np.abs(z) < 5.0), (F, np.round(z, 2), s.avg[2], rz)
+            assert abs(s.avg[0]) < 5 * s.stderr[0] and abs(s.avg[1]) < 5 * s.stderr[1]
+            assert 0.15 < s.acceptance_ratio < 0.75, (F, s.acceptance_ratio)   # the band holds it (0.6 at small F: steps saturate)
+            assert s.avg[7] == 0.0 and s.avg[9] == 0.0                           # E0 = 0: no dipoles
+
+
+@pytest.mark.parametrize("n,nsteps", [(64, 1500), (100, 1000), (200, 500)], ids=["n64-M1", "n100-M2", "n200-M4"])
+def test_f32_all_pairs_kernels_against_oracle_and_f64(ps, oracle, n, nsteps):
+    """interacting_kernel<float, M = 1 | 2 | 4>: M >= 2 runs the packed ring sum (ring_pair_sum_pk), a different
+    LDS layout and code path from M = 1 and from the f64 template.  (i) a zero-step launch: the initial pair
+    energy of the same angles agrees with the f64 kernel's to f32 rounding; (ii) a short pre-collapse run:
+    pooled means within 4.5 sigma of the oracle's literal O(n^2) mode; (iii) same seeds, f32 vs f64."""
+    kw = dict(n=n, E0=1.0, K1=1.0, K2=0.0, Fz=0.5, energy_type=ps.INTERACTING, seed=31)
+    # (i)
+    U0 = {}
+    for prec in (ps.F32, ps.F64):
+        with ps.Ensemble(ps.default_params(num_chains=64, precision=prec, **kw)) as e:
+            U0[prec] = np.array([e.microstate(c) for c in range(64)])
+    scale = np.abs(U0[ps.F64][:, 6]) + n * 0.5
+    assert np.all(np.abs(U0[ps.F32][:, 6] - U0[ps.F64][:, 6]) < 3e-5 * scale), np.abs(U0[ps.F32][:, 6] - U0[ps.F64][:, 6]).max()
+    np.testing.assert_allclose(U0[ps.F32][:, :6], U0[ps.F64][:, :6], rtol=0, atol=2e-4)
+    # (ii) + (iii)
+    nch = 1024
+    res = {}
+    for prec in (ps.F32, ps.F64):
+        op, pp = both(nsteps, num_chains=nch if prec == ps.F32 else 256, precision=prec, **kw)
+        with ps.Ensemble(pp) as e:
+            e.advance(nsteps)
+            res[prec] = e.rolling() + (e.summary(),)
+    osums, onorm, _ = oracle.run_many(op, 7_000_000, 96, nthreads=8, mode="faithful")
+    o_avg, o_se = pooled(osums, onorm)
+    g_avg, g_se, s32 = res[ps.F32]
+    z = (g_avg - o_avg) / np.sqrt(g_se ** 2 + o_se ** 2 + 1e-300)
+    assert np.all(np.abs(z) < 4.5), dict(zip(ps.OBS_NAMES, np.round(z, 2)))
+    d_avg, d_se, s64 = res[ps.F64]
+    z2 = (g_avg - d_avg) / np.sqrt(g_se ** 2 + d_se ** 2 + 1e-300)
+    assert np.all(np.abs(z2) < 4.5), dict(zip(ps.OBS_NAMES, np.round(z2, 2)))
+    assert abs(s32.acceptance_ratio - s64.acceptance_ratio) < 5 * np.hypot(s32.ar_stderr, s64.ar_stderr) + 2e-3
+
+
+def test_config4_as_stated_f32_against_f64(ps):
+    """BASELINE configs[3] exactly as stated: interacting dielectric chain, n = 64, E0 = 1, K1 = 1, K2 = 0, Fz = 0.5,
+    kT = b = 1, 16 384 chains x 2e4 steps from random starts.  Without excluded volume (inc/eap_chain.jl:200-207)
+    chains fall into the 1/r^3 singularity -- the reference's behaviour -- so <U> is dominated by how deep each
+    precision can fall before its arithmetic saturates and is NOT compared.  What is compared, f32 against f64 as
+    two independent samples (different seeds: same-seed trajectories diverge at the first near-singular step
+    anyway): <r>, <p>, AR and the fraction of collapsed chains."""
+    kw = dict(n=64, E0=1.0, K1=1.0, K2=0.0, Fz=0.5, energy_type=ps.INTERACTING, num_chains=16384)
+    out = {}
+    for prec, seed in ((ps.F32, 51), (ps.F64, 52)):
+        with ps.Ensemble(ps.default_params(precision=prec, seed=seed, **kw)) as e:
+            e.advance(20000)
+            out[prec] = e.summary()
+    a, b = out[ps.F32], out[ps.F64]
+    for k in (0, 1, 2, 7, 8, 9):
+        z = (a.avg[k] - b.avg[k]) / np.hypot(a.stderr[k], b.stderr[k])
+        assert abs(z) < 5.0, (ps.OBS_NAMES[k], a.avg[k], b.avg[k], z)
+    assert abs(a.acceptance_ratio - b.acceptance_ratio) < 5 * np.hypot(a.ar_stderr, b.ar_stderr)
+    fa, fb = a.chains_collapsed / 16384, b.chains_collapsed / 16384
+    assert abs(fa - fb) < 5 * np.sqrt((fa * (1 - fa) + fb * (1 - fb)) / 16384) + 0.01, (fa, fb)
+
+
+def test_failure_counters(ps, oracle):
+    """nan_rejects / chains_collapsed (ABI v5).  Non-interacting: identically zero.  A strongly coupled polar Ising
+    chain runs into r -> 0 between neighbours (the reference's behaviour): collapse is reported, and
+    the f64 kernel's count of non-finite trial energies equals the oracle's on the same streams."""
+    with ps.Ensemble(ps.default_params(num_chains=256, n=30, E0=1.0, Fz=1.0, seed=2)) as e:
+        e.advance(3000)
+        s = e.summary()
+        assert s.nan_rejects == 0 and s.chains_collapsed == 0
+    kw = dict(n=12, E0=1.0, mu=2.0, Fz=0.2, chain_type=ps.POLAR, energy_type=ps.ISING, seed=8)
+    for prec in (ps.F32, ps.F64):
+        with ps.Ensemble(ps.default_params(num_chains=512, precision=prec, **kw)) as e:
+            e.advance(20000)
+            s = e.summary()
+            assert s.chains_collapsed > 256, (prec, s.chains_collapsed)
+            assert abs(s.avg[14]) > 1e6 * 12
+            red = e.reduce_host()
+            assert red[ps.NRED - 2] == s.nan_rejects and red[ps.NRED - 1] == s.chains_collapsed
+            e.reset_averages()
+            assert e.summary().nan_rejects == 0

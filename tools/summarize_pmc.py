@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<tag>/ (tools/collect_pmc.sh) -> profiles/<round>/<name>_{kernel_trace,pmc}.csv and, with --record KEY,
+an entry in profiles/pmc_traffic.json (what bench.py's `roofline.traffic` and `valu.ops_per_update` read), stamped
+with the sha256 of the kernel sources it was collected on.
+
+    python tools/summarize_pmc.py gpurun_out/prof_f64 profiles/r02 sweep_f64 --kernel sweep_kernel \
+           --updates 6553600000 --record f64_n100_c65536_s100000
+
+Every figure EXCLUDES the first dispatch of the kernel (the warm-up launch)."""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src"); ap.add_argument("dst"); ap.add_argument("name")
+    ap.add_argument("--kernel", default="sweep_kernel")
+    ap.add_argument("--updates", type=float, default=0.0, help="attempted updates per launch")
+    ap.add_argument("--record", default=None)
+    a = ap.parse_args()
+    os.makedirs(a.dst, exist_ok=True)
+    cmd = open(os.path.join(a.src, "command.txt")).read().strip()
+
+    # kernel trace: per-dispatch durations of the kernel, warm-up launch dropped
+    tr = glob.glob(os.path.join(a.src, "trace", "**", "*kernel_trace.csv"), recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(tr)) if a.kernel in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    full = [d for d in dur[1:] if d > 0.5 * max(dur[1:])]
+    kname = rows[0]["Kernel_Name"]
+    with open(os.path.join(a.dst, a.name + "_kernel_trace.csv"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python3 {cmd}\n")
+        f.write("# per-dispatch durations of the kernel; the first dispatch (warm-up) is excluded from the summary row\n")
+        f.write("kernel,dispatches_total,dispatches_summarised,avg_ms,min_ms,max_ms,first_dispatch_ms\n")
+        f.write(f"\"{kname}\",{len(dur)},{len(full)},{sum(full) / len(full):.6f},{min(full):.6f},{max(full):.6f},{dur[0]:.6f}\n")
+        st = glob.glob(os.path.join(a.src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+        if st:
+            f.write("# rocprofv3's own --stats table of the same run (all dispatches, warm-up included):\n")
+            for line in open(st[0]):
+                f.write("# " + line)
+    kern_ms = sum(full) / len(full)
+
+    # PMC passes: sum over the XCD/SE instances of a dispatch, then mean over the non-warm-up dispatches
+    per = collections.defaultdict(dict)
+    kinfo = None
+    for fn in glob.glob(os.path.join(a.src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if a.kernel not in r["Kernel_Name"]:
+                continue
+            d = per[r["Counter_Name"]]
+            d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+            kinfo = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "VGPR_Count", "Accum_VGPR_Count",
+                                        "SGPR_Count", "LDS_Block_Size") if k in r}
+    mean = {}
+    lines = [f"# rocprofv3 --pmc <group> --kernel-trace -- python3 {cmd}   (one counter group per run)",
+             "# kernel: " + json.dumps(kinfo),
+             "# rows: mean over the kernel's dispatches EXCEPT its first one (the warm-up launch)",
+             "counter,dispatches,mean_per_dispatch,min,max"]
+    for name in sorted(per):
+        ids = sorted(per[name])
+        v = [per[name][i] for i in ids[1:]] or [per[name][ids[0]]]
+        v = [x for x in v if x >= 0.5 * max(v)] or v
+        mean[name] = sum(v) / len(v)
+        lines.append(f"{name},{len(v)},{mean[name]:.6g},{min(v):.6g},{max(v):.6g}")
+    if a.updates and "SQ_INSTS_VALU" in mean:
+        lines.append(f"# VALU wave-instructions per update per lane (x64 lanes / updates): {mean['SQ_INSTS_VALU'] * 64 / a.updates:.4f}")
+    if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+        hbm = (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024
+        lines.append(f"# HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reads half: "
+                     f"MI355X_MICROARCH.md, HBM): {hbm:.6g}")
+    open(os.path.join(a.dst, a.name + "_pmc.csv"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    print("kernel avg ms (warm-up excluded):", kern_ms, "over", len(full), "dispatches; first:", dur[0])
+
+    if a.record:
+        import bench
+        path = os.path.join(os.path.dirname(a.dst.rstrip("/")), "pmc_traffic.json")
+        stamp = bench.kernel_source_hash()
+        try:
+            rec = json.load(open(path))
+            if rec.get("kernel_source_sha256_16") != stamp:
+                rec = {}
+        except Exception:
+            rec = {}
+        rec.setdefault("records", {})
+        rec["kernel_source_sha256_16"] = stamp
+        rec["note"] = ("collected by tools/collect_pmc.sh + tools/summarize_pmc.py; bench.py uses a record only while the "
+                       "sha256 of polymer_stats_amd/csrc/* + include/pstat.h still equals the stamp")
+        rec["records"][a.record] = {
+            "hbm_bytes_per_launch": (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024,
+            "fetch_size_kib": mean["FETCH_SIZE"], "write_size_kib": mean["WRITE_SIZE"],
+            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reads half, MI355X_MICROARCH.md HBM)",
+            "round": os.path.basename(a.dst.rstrip("/")),
+            "valu_wave_instructions_per_launch": mean["SQ_INSTS_VALU"],
+            "valu_instructions_per_update_per_lane": mean["SQ_INSTS_VALU"] * 64 / a.updates,
+            "kernel_ms_rocprof_trace": kern_ms,
+        }
+        json.dump(rec, open(path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
