@@ -268,10 +268,11 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   bool any_fx = false;
   for (auto &c : h->cases) any_fx = any_fx || c.Fx != 0.0;
   h->cfg = {h->base.precision, h->base.chain_type, h->base.energy_type, h->base.do_flips ? 1 : 0,
-            h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, 0, h->base.rng, h->base.move_set};
+            h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, 0, h->base.rng, h->base.move_set, 0};
+  h->cfg.state_global = f64_state_global(h->cfg, h->base.n) ? 1 : 0;
 
   const bool inter = all_pairs(h->base.energy_type);
-  int lanes = inter ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
+  int lanes = (inter || h->cfg.state_global) ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
   if (lanes == 0) {
     delete h;
     return fail(PSTAT_ERR_UNSUPPORTED, "num-monomers = %lld does not fit the 160 KiB LDS of a CU",
@@ -307,7 +308,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   } while (0)
 
   CREATE_HIP(hipSetDevice(h->device));
-  if (!inter) {
+  if (!inter && !h->cfg.state_global) {
     // Chains per workgroup (active lanes of its single wave).  State lives in LDS, so a CU holds at
     // most 160 KiB / (bytes per chain) chains; pick the lane count that minimises the makespan
     // max(1, workgroups / resident slots) of one launch -- e.g. f32, n = 100: 51 lanes x 4
@@ -358,6 +359,8 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_TRY(alloc(h, (void **)&S.nanrej, Cz * sizeof(int64_t)));
   const size_t nstate = h->bufs.size();
   CREATE_TRY(alloc(h, &S.ang_tmp, 2 * n * Cz * h->elem));
+  if (h->cfg.state_global)   // working copy of the cells, [chain block][n][64] double2 (run_segment, ST = 2)
+    CREATE_TRY(alloc(h, &S.work, (size_t)(A.blocks_per_case * ncases) * n * 64 * 16));
   CREATE_TRY(alloc(h, (void **)&h->d_cases, sizeof(CaseConst) * (size_t)ncases));
   CREATE_TRY(alloc(h, (void **)&h->d_queue, sizeof(int) * sweep_queue_ints(h->args)));
   CREATE_TRY(alloc(h, (void **)&h->d_partial, sizeof(double) * reduce_scratch_doubles()));

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64) void cluster_kernel(SweepArgs A, DevState S, co
                                                      int umbrella, int *__restrict__ queue) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
-  run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len) {
+  run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len, int) {
     run_cluster_segment<R, G, CT, EN, ST>(A, S, cc, umbrella, smem, lane, chain, first, len);
   }, cases);
 }

@@ -37,6 +37,9 @@ struct DevState {
   double *uref;         // f64[C]         sum(u) of the chain's first configuration: the umbrella weights
                         //                are taken relative to it (a per-chain constant factor cancels
                         //                in value/normalizer, inc/average.jl:38,63-67)
+  void *work;           // f64 "global state" sweep only: the wave's working copy of its chains' (theta, phi) cells,
+                        //                [chain block][n][64] double2, random-accessed through L2 / Infinity Cache while a
+                        //                segment runs (filled from / spilled to `ang` like LDS is); not checkpointed
   int64_t *nanrej;      // i64[C]         proposals whose trial energy was NaN or +-Inf (1/r^3 singularities of the
                         //                pair energies; the reference rejects them silently, inc/acceptance.jl:29-39)
   int64_t C;
@@ -194,7 +197,7 @@ struct Mwc64x {
 // (placement-independent; cdna_hip_programming.md Guideline 16).  Deadlock-free for any residency: a
 // job's predecessor was handed out earlier, to a workgroup that is running and that itself only ever
 // waits on still earlier jobs; the wait is bounded (max_spins) and a timeout is reported through the
-// queue's error word.  `body(case constants, global chain, first step, number of steps)` runs one
+// queue's error word.  `body(case constants, global chain, first step, number of steps, chain block)` runs one
 // segment of one lane's chain.
 template <typename Body>
 __device__ __forceinline__ void run_job_queue(const SweepArgs &A, int *__restrict__ queue, const int lane, Body &&body,
@@ -231,7 +234,7 @@ __device__ __forceinline__ void run_job_queue(const SweepArgs &A, int *__restric
     const int64_t len = left < A.seg_len ? left : A.seg_len;
     // lanes own disjoint LDS columns and never exchange data: idle lanes just skip the body
     if (len > 0 && lane < A.lanes && local < A.chains_per_case)
-      body(cases[icase], icase * A.chains_per_case + local, A.step0 + first, len);
+      body(cases[icase], icase * A.chains_per_case + local, A.step0 + first, len, blk);
     if (A.nseg > 1) {
       // publish: this wave's spill stores are complete and written back before the counter moves
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -249,6 +252,7 @@ struct LaunchCfg {
   int lag;  // a re-init has happened on this handle
   int rng;  // PSTAT_RNG_MWC64X | PSTAT_RNG_XOSHIRO128PP
   int move_set;  // PSTAT_MOVES_SINGLE (mcmc_eap_chain.jl) | PSTAT_MOVES_CLUSTER (mcmc_clustering_eap_chain.jl)
+  int state_global;  // f64 sweep: state cells in the global working buffer (DevState::work) instead of LDS
 };
 hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                        const CaseConst *cases, double phi_step, double theta_step,
@@ -275,6 +279,7 @@ size_t reduce_scratch_doubles();
 hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
                              int *blocks_per_cu, const char **name);
 int choose_lanes(int precision, int64_t n, int energy_type);
+bool f64_state_global(const LaunchCfg &cfg, int64_t n);   // the f64 sweep of this configuration keeps its state in DevState::work
 // --energy-type interacting: one chain per wavefront (pstat_interacting.hip), n <= 256
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                               const CaseConst *cases, int reinit_mode, hipStream_t stream);

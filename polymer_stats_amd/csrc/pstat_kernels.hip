@@ -144,16 +144,24 @@ struct SweepRare {  // wave-uniform switches of the rarely used options (RARE in
 template <typename R, typename G, int CT, int EN, bool FX, bool RARE, int ST>
 __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &S, const CaseConst &cc,
                                             const SweepRare rare, unsigned char *smem, const int lane,
-                                            const int64_t c, int64_t step, int64_t remaining) {
+                                            const int64_t c, int64_t step, int64_t remaining, const int blk) {
   using R2 = typename Vec2<R>::type;
   using AG = Ang<R>;
   // ST = 0: the LDS cell is the (theta, phi) pair in R.  ST = 1 (PSTAT_Q16, R = float): the cell is
   // one 32-bit word, theta lattice index in the low half and phi index in the high half.
+  // ST = 2 (R = double): the cells live in GLOBAL memory -- DevState::work, [chain block][n][64] double2 -- and are
+  // random-accessed through L2 / the Infinity Cache.  An f64 cell is 16 bytes: at n = 100 LDS seats 102 chains per CU
+  // (two 51-lane waves on two of the four SIMDs); with the cells in memory every SIMD carries a full 64-lane wave.
+  // The f64 step is ~470 instructions (~2300 cycles) long, so the one-step-ahead prefetch of the pipeline below
+  // covers an Infinity-Cache hit (~550 cycles) several times over.
   constexpr bool Q = ST == 1;
+  constexpr bool GM = ST == 2;
   static_assert(!Q || sizeof(R) == 4, "the lattice state runs on f32 arithmetic");
+  static_assert(!GM || (sizeof(R) == 8 && EN == PSTAT_NONINTERACTING), "global-memory state: f64, non-interacting");
   using Cell = typename std::conditional<Q, uint32_t, R2>::type;
-  Cell *ang = reinterpret_cast<Cell *>(smem);  // [n][lanes]
-  const int lanes = A.lanes;
+  const int lanes = GM ? 64 : A.lanes;
+  unsigned char *const cells = GM ? reinterpret_cast<unsigned char *>(S.work) + (size_t)blk * (size_t)A.n * 64 * sizeof(Cell) : smem;
+  Cell *ang = reinterpret_cast<Cell *>(cells);  // [n][lanes]
   const int64_t C = S.C;
   const int n = (int)A.n;
 
@@ -221,7 +229,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // prefetched row is replaced by the freshly accepted angles.
   using P = typename V2<R>::type;   // a 2-vector: (x, y), {n_z, mu_z}, (theta, phi) or {old, new}
   const uint32_t row_bytes = (uint32_t)lanes * (uint32_t)sizeof(Cell), lane_bytes = (uint32_t)lane * (uint32_t)sizeof(Cell);
-  auto slot = [&](uint32_t off) __attribute__((always_inline)) -> Cell & { return *reinterpret_cast<Cell *>(smem + off); };
+  auto slot = [&](uint32_t off) __attribute__((always_inline)) -> Cell & { return *reinterpret_cast<Cell *>(cells + off); };
   Draw dA = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes), dB = dA;
   Cell aA = slot(dA.cell), aB = aA;
   R phistep3 = 3 * phistep, thstep3 = 3 * thstep;
@@ -619,8 +627,8 @@ __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
                                                    SweepRare rare, int *__restrict__ queue) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
-  run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len) {
-    run_segment<R, G, CT, EN, FX, RARE, ST>(A, S, cc, rare, smem, lane, chain, first, len);
+  run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len, int blk) {
+    run_segment<R, G, CT, EN, FX, RARE, ST>(A, S, cc, rare, smem, lane, chain, first, len, blk);
   }, cases);
 }
 
@@ -791,10 +799,14 @@ __global__ void reinit_kernel(SweepArgs A, DevState S, const CaseConst *__restri
 using SweepFn = void (*)(SweepArgs, DevState, const CaseConst *, SweepRare, int *);
 
 #ifdef PSTAT_PART
-// One object per state format: 1 = f32 (turns), 2 = q16 (lattice, f32 arithmetic), 3 = f64.
+// One object per state format: 1 = f32 (turns), 2 = q16 (lattice, f32 arithmetic), 3 = f64 with the cells in LDS,
+// 4 = f64 with the cells in global memory (non-interacting energy only).
 template <typename G, int CT, int EN, bool FX, bool RARE>
 static SweepFn pick_state() {
-#if PSTAT_PART == 3
+#if PSTAT_PART == 4
+  if constexpr (EN == PSTAT_NONINTERACTING) return sweep_kernel<double, G, CT, EN, FX, RARE, 2>;
+  else return nullptr;
+#elif PSTAT_PART == 3
   return sweep_kernel<double, G, CT, EN, FX, RARE, 0>;
 #elif PSTAT_PART == 2
   return sweep_kernel<float, G, CT, EN, FX, RARE, 1>;
@@ -817,7 +829,9 @@ static SweepFn pick_model(const LaunchCfg &cfg) {
   return ising ? pick_flags<G, PSTAT_POLAR, PSTAT_ISING>(cfg)
                : pick_flags<G, PSTAT_POLAR, PSTAT_NONINTERACTING>(cfg);
 }
-#if PSTAT_PART == 3
+#if PSTAT_PART == 4
+SweepFn pick_sweep_f64g(const LaunchCfg &cfg) {
+#elif PSTAT_PART == 3
 SweepFn pick_sweep_f64(const LaunchCfg &cfg) {
 #elif PSTAT_PART == 2
 SweepFn pick_sweep_q16(const LaunchCfg &cfg) {
@@ -832,6 +846,18 @@ SweepFn pick_sweep_f32(const LaunchCfg &cfg) {
 SweepFn pick_sweep_f32(const LaunchCfg &cfg);
 SweepFn pick_sweep_q16(const LaunchCfg &cfg);
 SweepFn pick_sweep_f64(const LaunchCfg &cfg);
+SweepFn pick_sweep_f64g(const LaunchCfg &cfg);
+
+// f64 cells are 16 bytes: LDS seats 160 KiB / (16 n) chains per CU.  Once that is fewer than four full waves
+// (n > 40) the non-interacting f64 sweep keeps its cells in global memory instead and runs 64 lanes on every
+// SIMD (run_segment, ST = 2).  PSTAT_F64_STATE=lds|global overrides the choice (experiments, tests).
+bool f64_state_global(const LaunchCfg &cfg, int64_t n) {
+  if (cfg.precision != PSTAT_F64 || cfg.move_set != PSTAT_MOVES_SINGLE || cfg.energy_type != PSTAT_NONINTERACTING) return false;
+  const char *e = getenv("PSTAT_F64_STATE");
+  if (e && e[0] == 'l') return false;
+  if (e && e[0] == 'g') return true;
+  return n * 16 * 256 > 160 * 1024;
+}
 
 static int cell_bytes(int precision) { return precision == PSTAT_F64 ? 16 : (precision == PSTAT_Q16 ? 4 : 8); }
 
@@ -845,11 +871,13 @@ int choose_lanes(int precision, int64_t n, int energy_type) {
 }
 
 static SweepFn pick_sweep(const LaunchCfg &cfg) {
+  if (cfg.precision == PSTAT_F64 && cfg.state_global) return pick_sweep_f64g(cfg);
   return cfg.precision == PSTAT_F64 ? pick_sweep_f64(cfg)
        : (cfg.precision == PSTAT_Q16 ? pick_sweep_q16(cfg) : pick_sweep_f32(cfg));
 }
 
 static int sweep_lds_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
+  if (cfg.state_global) return 0;
   return (int)(a.n * a.lanes * cell_bytes(cfg.precision));
 }
 
@@ -864,7 +892,7 @@ hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_
   if (e != hipSuccess) return e;
   if (lds_bytes) *lds_bytes = lds;
   if (blocks_per_cu) *blocks_per_cu = nb;
-  if (name) *name = cfg.precision == PSTAT_F64 ? "sweep_kernel<double>"
+  if (name) *name = cfg.precision == PSTAT_F64 ? (cfg.state_global ? "sweep_kernel<double, state in L2>" : "sweep_kernel<double>")
                  : (cfg.precision == PSTAT_Q16 ? "sweep_kernel<float, q16 state>" : "sweep_kernel<float>");
   return hipSuccess;
 }
