@@ -140,8 +140,9 @@ typedef struct pstat_summary {
    * pair energies (inc/eap_chain.jl:200-207,215-228: 1/r^3) a chain can fall into r -> 0 and stay there.
    *   nan_rejects       proposals, over all chains and recorded steps, whose trial energy was NaN or +-Inf
    *                     (identically 0 for the non-interacting energy, whose dU is always finite);
-   *   chains_collapsed  chains whose CURRENT energy has |U| > 1e6 * n * kT -- no bounded-field configuration
-   *                     of separated monomers gets there; only a 1/r^3 singularity does. */
+   *   chains_collapsed  chains whose CURRENT energy has |U| > 1e3 * n * (kT + |E0| mu_max / 2 + b (|Fx| + |Fz|)),
+   *                     mu_max = max(|K1|, |K2|) |E0| or |mu|: a thousand times what n separated monomers can hold
+   *                     in field, force and thermal energy; only a 1/r^3 contact gets there (also counts NaN). */
   int64_t nan_rejects;
   int64_t chains_collapsed;
 } pstat_summary;

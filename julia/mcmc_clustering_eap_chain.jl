@@ -180,7 +180,7 @@ function report_failures(sm)
   sm.nan_rejects > 0 &&
     @warn "$(sm.nan_rejects) proposals had a non-finite energy and were rejected";
   sm.chains_collapsed > 0 &&
-    @warn "$(sm.chains_collapsed) of $(sm.num_chains) chains have collapsed (|U| > 1e6 n kT: monomers on top of each other)";
+    @warn "$(sm.chains_collapsed) of $(sm.num_chains) chains have collapsed (|U| a thousand times beyond field + force + thermal energy: monomers on top of each other)";
 end
 
 function pooled_summary(handles, steps)

@@ -680,9 +680,12 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_stage1(DevState S, int64_t
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { m1[q] += v[q]; m2[q] = fma(v[q], v[q], m2[q]); }
     mx[0] += (double)S.nanrej[c];
-    // collapsed: |U| of the current configuration beyond anything separated monomers in a bounded field reach
-    const double Unow = S.obs[OBS_U * C + c];
-    mx[1] += !(fabs(Unow) <= 1e6 * (double)n * cases[c / chains_per_case].kT) ? 1.0 : 0.0;
+    // collapsed: |U| of the current configuration is 1e3 times beyond what n separated monomers can hold in field,
+    // force and thermal energy -- only a 1/r^3 contact gets there (pstat.h, pstat_summary.chains_collapsed)
+    const CaseConst &cc = cases[c / chains_per_case];
+    const double mu_max = fmax(fmax(fabs(cc.K1), fabs(cc.K2)) * fabs(cc.E0), fabs(cc.mu));
+    const double per_monomer = cc.kT + 0.5 * fabs(cc.E0) * mu_max + fabs(cc.b) * (fabs(cc.Fx) + fabs(cc.Fz));
+    mx[1] += !(fabs(S.obs[OBS_U * C + c]) <= 1e3 * (double)n * per_monomer) ? 1.0 : 0.0;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll

@@ -257,7 +257,7 @@ class _Pool:
                                       f"({s.nan_rejects / max(1.0, s.attempted_updates):.3g} of all attempts)")
         if s.chains_collapsed:
             _log(pargs, 2, "Warning", f"{s.chains_collapsed} of {s.num_chains} chains have collapsed "
-                                      f"(|U| > 1e6 n kT: monomers on top of each other)")
+                                      f"(|U| a thousand times beyond field + force + thermal energy: monomers on top of each other)")
 
     def microstate(self):
         return self.parts[0].microstate(0)

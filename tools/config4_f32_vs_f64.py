@@ -24,7 +24,7 @@ for name, prec, seed in (("f32", ps.F32, 51), ("f64", ps.F64, 52), ("f64_second_
     res[name] = s
     out[name] = {"seed": seed, "avg": dict(zip(ps.OBS_NAMES, s.avg)), "stderr": dict(zip(ps.OBS_NAMES, s.stderr)),
                  "AR": s.acceptance_ratio, "AR_stderr": s.ar_stderr, "nan_rejects": s.nan_rejects,
-                 "chains_collapsed_abs_U_gt_1e6_n_kT": s.chains_collapsed,
+                 "chains_collapsed": s.chains_collapsed,
                  "final_U_quantiles_of_1024_chains": dict(zip(("q05", "q25", "q50", "q75", "q95"),
                                                               np.quantile(U, [0.05, 0.25, 0.5, 0.75, 0.95]).tolist()))}
 for a, b in (("f32", "f64"), ("f64_second_seed", "f64")):
