@@ -288,6 +288,13 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   A.lanes = lanes;
   A.adaptive = (h->base.adj_scale != 1.0 && h->base.steps_per_adjust > 0) ? 1 : 0;  // mcmc_eap_chain.jl:302
   A.ncases = ncases; A.seg_len = 0; A.nseg = 1; A.max_spins = 1 << 22;
+  A.lds_rows = 0; A.pad_ = 0;
+  if (h->cfg.state_global) {   // a quarter of a CU's LDS per wave: four resident waves, 64 lanes x 16 B per row
+    int rows = 160 * 1024 / 4 / (64 * 16) - 1;   // one row of the quarter is the trash row of run_segment
+    const char *e = getenv("PSTAT_F64_LDS_ROWS");
+    if (e && atoi(e) >= 0 && atoi(e) <= rows) rows = atoi(e);
+    A.lds_rows = (int32_t)(h->base.n < rows ? h->base.n : rows);
+  }
   if ((int64_t)A.blocks_per_case * ncases > 0x7fffffffLL) {
     delete h;
     return fail(PSTAT_ERR_INVALID_ARG, "too many chains for one launch");

@@ -73,6 +73,8 @@ struct SweepArgs {
   int64_t seg_len;           // steps per time segment (job) of this launch
   int32_t nseg;              // segments per chain block in this launch
   int32_t max_spins;         // bound on the predecessor wait (each spin sleeps ~2 us)
+  int32_t lds_rows;          // f64 state-in-memory sweep: monomers [0, lds_rows) keep their cells in LDS
+  int32_t pad_;
 };
 
 // ---------------------------------------------------------------------------------------------

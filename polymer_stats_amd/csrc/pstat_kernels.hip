@@ -189,7 +189,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       R2 v;
       v.x = gth[(int64_t)i * C + c];
       v.y = gph[(int64_t)i * C + c];
-      ang[i * lanes + lane] = v;
+      if (GM && i < A.lds_rows) reinterpret_cast<Cell *>(smem)[i * lanes + lane] = v;
+      else ang[i * lanes + lane] = v;
     }
   }
   // step sizes in the unit the proposal is added in: radians (f64), turns (f32), lattice cells (q16)
@@ -230,8 +231,61 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   using P = typename V2<R>::type;   // a 2-vector: (x, y), {n_z, mu_z}, (theta, phi) or {old, new}
   const uint32_t row_bytes = (uint32_t)lanes * (uint32_t)sizeof(Cell), lane_bytes = (uint32_t)lane * (uint32_t)sizeof(Cell);
   auto slot = [&](uint32_t off) __attribute__((always_inline)) -> Cell & { return *reinterpret_cast<Cell *>(cells + off); };
+  // GM: rows [0, nL) of the wave's cells sit in LDS (as many as four resident waves per CU can share), the rest in
+  // memory.  One CU sustains only about three waves' worth of divergent 16-byte accesses per step (measured: 3 waves per
+  // CU run at full speed, the 4th stretches every step by 50 %), so every access kept on chip counts.  Which home a
+  // lane's monomer has differs from lane to lane; to keep the step ONE basic block (branches would cost the exact
+  // vmcnt/lgkmcnt counts that the prefetch depends on) every step issues both a ds_read and a buffer_load, both a
+  // ds_write and a buffer_store, and steers each lane by its ADDRESS: the memory side goes through a buffer resource
+  // whose bounds check drops an out-of-range offset (no traffic, a load returns 0), the LDS side is pointed at a trash
+  // row.  A rejected step is steered away on both sides, so it stores nothing.
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  struct RowG { Cell l; v4i g; };
+  using Row = typename std::conditional<GM, RowG, Cell>::type;
+  const uint32_t nL = GM ? (uint32_t)A.lds_rows : 0u;
+  const uint32_t trash = nL * row_bytes + lane_bytes;        // LDS row nL: never read for its contents
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(GM ? (void *)cells : (void *)nullptr, 0,
+                                                                  GM ? (int)((uint32_t)n * row_bytes) : 0, 0x00020000);
+  auto rdrow = [&](const Draw &d) __attribute__((always_inline)) -> Row {
+    if constexpr (GM) {
+      const bool inL = d.idx < nL;
+      RowG r;
+      r.l = *reinterpret_cast<Cell *>(smem + (inL ? d.cell : trash));
+      r.g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, inL ? 0xFFFFFFFFu : d.cell, 0, 0);
+      return r;
+    } else {
+      return slot(d.cell);
+    }
+  };
+  auto wr = [&](const Draw &d, const Cell v, const bool ok) __attribute__((always_inline)) {
+    if constexpr (GM) {
+      const bool inL = d.idx < nL;
+      *reinterpret_cast<Cell *>(smem + ((ok && inL) ? d.cell : trash)) = v;
+      typedef double v2dd __attribute__((ext_vector_type(2)));
+      const v2dd vv = {v.x, v.y};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, vv), rsrc, (ok && !inL) ? d.cell : 0xFFFFFFFFu, 0, 0);
+    } else {
+      slot(d.cell) = v;
+    }
+  };
   Draw dA = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes), dB = dA;
-  Cell aA = slot(dA.cell), aB = aA;
+  Row aA = rdrow(dA), aB = aA;
+  // Cells in memory (GM): the pipeline is TWO steps deep -- three (draw, row) register sets, step s issues the load of
+  // step s + 2 -- because a load that misses L2 comes back from the Infinity Cache in more than one step's time once
+  // every CU is issuing them (measured with a one-step pipeline: 27 % of the wave's cycles spent waiting).  A row is
+  // therefore loaded BEFORE the stores of the two steps that precede its use; their committed cells are forwarded
+  // into it at its first use (fw1 = previous step, fw2 = the one before; ~0 = no such cell).
+  Draw dC = dA;
+  Row aC = aA;
+  Cell fw1_cell{}, fw2_cell{};
+  uint32_t fw1_at = ~0u, fw2_at = ~0u;
+  (void)dC; (void)aC; (void)fw1_cell; (void)fw2_cell; (void)fw1_at; (void)fw2_at;
+  if constexpr (GM) {
+    if (remaining > 1) {
+      dB = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes);
+      aB = rdrow(dB);
+    }
+  }
   R phistep3 = 3 * phistep, thstep3 = 3 * thstep;
   (void)phistep3; (void)thstep3;
   P stepv = {thstep, phistep}, step3v = {thstep3, phistep3};   // f32: the (theta, phi) proposal as one 2-vector
@@ -293,11 +347,23 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     R accw = 0;
 
     // one Monte-Carlo step on (d, a0); fetches the next step's draws and LDS row into (dn, an)
-    auto one_step = [&](const Draw &d, const Cell &a0, Draw &dn, Cell &an, const bool more)
+    auto one_step = [&](const Draw &d, const Row &a0_, Draw &dn, Row &an, const bool more)
         __attribute__((always_inline)) {
+      Cell a0;
+      if constexpr (GM) {   // the row's home, then the two preceding commits forwarded into it, the older one first
+        typedef double v2dd __attribute__((ext_vector_type(2)));
+        const v2dd gv = __builtin_bit_cast(v2dd, a0_.g);
+        const bool inL = d.idx < nL;
+        a0.x = inL ? a0_.l.x : gv.x; a0.y = inL ? a0_.l.y : gv.y;
+        const bool s2 = fw2_at == d.cell, s1 = fw1_at == d.cell;
+        a0.x = s2 ? fw2_cell.x : a0.x; a0.y = s2 ? fw2_cell.y : a0.y;
+        a0.x = s1 ? fw1_cell.x : a0.x; a0.y = s1 ? fw1_cell.y : a0.y;
+      } else {
+        a0 = a0_;
+      }
       if (more) {
         dn = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes);
-        an = slot(dn.cell);
+        an = rdrow(dn);
         // keep the next row's read up here, a whole step ahead of its use: left alone, the scheduler sinks it
         // to ~12 instructions before the forwarding select, and a lone wave then waits for LDS (+1 % measured)
         __builtin_amdgcn_sched_barrier(0);
@@ -480,7 +546,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       Cell a1;
       if constexpr (Q) a1 = ok ? cell1 : a0;
       else { a1.x = ok ? th1 : th0; a1.y = ok ? ph1 : ph0; }
-      slot(d.cell) = a1;
+      wr(d, a1, ok);
       const R m = ok ? (R)1 : (R)0;
       const P mm = {m, m};
       if constexpr (sizeof(R) == 8) {  // the oracle's update order: r += b*dn, p += dm, U += dU
@@ -499,10 +565,13 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       }
       nacc_seg += ok ? 1 : 0;
       if constexpr (EN == PSTAT_ISING) nnan_seg += not_finite(dU) ? 1 : 0;
-      if (more) {  // forward the accepted angles into the prefetched row if it is the same monomer
+      if constexpr (GM) {
+        fw2_cell = fw1_cell; fw2_at = fw1_at;
+        fw1_cell = a1; fw1_at = d.cell;
+      } else if (more) {  // forward the accepted angles into the prefetched row if it is the same monomer
         const bool same = dn.cell == d.cell;
         if constexpr (Q) an = same ? a1 : an;
-        else { an.x = same ? a1.x : an.x; an.y = same ? a1.y : an.y; }
+        else if constexpr (!GM) { an.x = same ? a1.x : an.x; an.y = same ? a1.y : an.y; }
       }
 
       // ---- record! x 8, mcmc_eap_chain.jl:327-328 (every step, accepted or not)
@@ -530,6 +599,23 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     // (f64: two steps per block -- its step is ~550 instructions, eight of them overflow the 64 KiB
     // instruction cache)
     constexpr int UNROLL = sizeof(R) == 8 ? 2 : (EN == PSTAT_ISING ? PSTAT_UNROLL_ISING : PSTAT_UNROLL);
+    if constexpr (GM) {
+      // Cells in memory: loads and stores share one in-order counter (vmcnt), so a wait for a prefetched row must know
+      // exactly how many younger operations are in flight, or it ends up waiting for the previous step's STORE as well.
+      // The main loop therefore prefetches unconditionally and the segment's last steps run in the tail.
+      // (`more` of a step = a step two after it exists in this segment; the main loop covers only such steps)
+      const int lim = chunk < left - 2 ? chunk : left - 2;
+      for (; k + 3 <= lim; k += 3) {
+        one_step(dA, aA, dC, aC, true);
+        one_step(dB, aB, dA, aA, true);
+        one_step(dC, aC, dB, aB, true);
+      }
+      for (; k < chunk; ++k) {
+        one_step(dA, aA, dC, aC, left - k > 2);
+        dA = dB; aA = aB;
+        dB = dC; aB = aC;
+      }
+    } else {
     for (; k + (UNROLL - 1) < chunk; k += UNROLL) {
 #pragma unroll
       for (int u = 0; u < UNROLL; u += 2) {
@@ -544,6 +630,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     if (k < chunk) {
       one_step(dA, aA, dB, aB, left - k > 1);
       dA = dB; aA = aB;
+    }
     }
 
     R acc1[7] = {a1rxy.x, a1rxy.y, a1z.x, a1pxy.x, a1pxy.y, a1z.y, a1U};
@@ -597,7 +684,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   } else {
     R *gth = (R *)S.ang, *gph = (R *)S.ang + (int64_t)n * C;
     for (int i = 0; i < n; ++i) {
-      const R2 v = ang[i * lanes + lane];
+      const R2 v = (GM && i < A.lds_rows) ? reinterpret_cast<Cell *>(smem)[i * lanes + lane] : ang[i * lanes + lane];
       gth[(int64_t)i * C + c] = v.x;
       gph[(int64_t)i * C + c] = v.y;
     }
@@ -880,7 +967,7 @@ static SweepFn pick_sweep(const LaunchCfg &cfg) {
 }
 
 static int sweep_lds_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
-  if (cfg.state_global) return 0;
+  if (cfg.state_global) return (a.lds_rows + 1) * 64 * 16;   // + the trash row
   return (int)(a.n * a.lanes * cell_bytes(cfg.precision));
 }
 
