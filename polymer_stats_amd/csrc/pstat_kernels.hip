@@ -174,6 +174,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   const R hb = (R)(-cc.b / 2);
   const R ising_scale = (R)(0.0795774715459476679 / fabs(cc.b * cc.b * cc.b / 8));   // f32 Ising: see the step
   const R nbeta_log2e = (R)(-1.4426950408889634 / cc.kT);  // exp(-dU/kT) = exp2(dU * this)
+  const double ninv_kT = -1.0 / cc.kT;
+  (void)ninv_kT;
   (void)Fx; (void)kT; (void)hb; (void)nbeta_log2e; (void)ising_scale;
 
   // ---- fill
@@ -370,8 +372,9 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       }
       // ---- proposal, mcmc_eap_chain.jl:277-280, and trial angles, inc/eap_chain.jl:232-236
       R eps;                        // u in [0,1) (f64) or 1 + u (f32: the -1 is folded into the test)
-      if constexpr (sizeof(R) == 8) eps = u01<R>(d.weps);
+      if constexpr (sizeof(R) == 8) eps = 0;   // (metropolis_f64 derives it from the raw word)
       else eps = bits12(d.weps);
+      (void)eps;
       R th0, ph0, th1, ph1;
       bool inside = true;           // q16: the trial theta stayed on the lattice (else: clamped => rejected)
       uint32_t cell1 = 0;           // q16: packed trial state
@@ -531,8 +534,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       R dw = 0;
       if constexpr (RARE) dw = du * wscale;   // change of the umbrella weight function (0 if off)
       if constexpr (sizeof(R) == 8) {
-        const R delta = -dU / kT + log_r(st1 / st0) + dw - lag;
-        ok = (delta >= 0) || (eps < exp_r(delta));
+        ok = metropolis_f64(dU, kT, ninv_kT, st1, st0, dw - lag, d.weps);
       } else {
         // same test with the logarithm folded away: eps * sin(th0) < sin(th1) * exp(-dU/kT + dw - lag)
         R e;

@@ -96,6 +96,32 @@ __device__ __forceinline__ R sym11(uint32_t w) {  // 2u - 1 in [-1,1)
   else return (R)2 * ((R)(w >> 9) * (R)(1.0 / 8388608.0)) - (R)1;
 }
 
+// The Metropolis test of the f64 kernels (inc/acceptance.jl:29-39 with the cached log-density written as a
+// difference):  ok = (delta >= 0) || (eps < exp(delta)),  delta = -dU/kT + log(st1/st0) + extra,  eps = u01(weps).
+// The literal expression costs a log, an exp and two divisions in double (~95 instructions).  Since eps < 1, the test
+// is  eps * st0 < st1 * exp(-dU/kT + extra)  wherever that product is finite, and an f32 evaluation of the two sides
+// (v_exp_f32, three conversions) decides it whenever they differ by more than the f32 error bound m: only draws
+// within a relative 1e-5 of the threshold -- one wave-step in ~1500 -- run the literal double expression, whose
+// verdict is then taken unchanged.  The decision is therefore ALWAYS the literal one (the bit-parity tests against
+// the oracle hold); the filter only spares its evaluation.  NaN, +-inf, underflow to 0 and eps = 0 all land in the
+// literal branch or on the side the literal test takes.
+__device__ __forceinline__ bool metropolis_f64(const double dU, const double kT, const double ninv_kT, const double st1,
+                                               const double st0, const double extra, const uint32_t weps) {
+  const float t = (float)(dU * ninv_kT + extra);
+  const float e = __builtin_amdgcn_exp2f(t * 1.44269504f);
+  const float lhs = (__uint_as_float(0x3F800000u | (weps >> 9)) - 1.0f) * (float)st0, rhs = e * (float)st1;
+  const float m = 2e-6f + 1e-6f * __builtin_fabsf(t);          // > 3x the f32 error of rhs / lhs
+  const bool acc = __builtin_fmaf(lhs, m, lhs) < rhs, rej = lhs > __builtin_fmaf(rhs, m, rhs);
+  bool ok = acc;
+  if (__builtin_amdgcn_ballot_w64(!(acc || rej)) != 0) {        // some lane is too close to call (or not finite)
+    const double delta = -dU / kT + log_f64(st1 / st0) + extra;
+    const double eps = (double)(weps >> 9) * (1.0 / 8388608.0);
+    const bool lit = (delta >= 0) || (eps < exp_f64(delta));
+    ok = (acc || rej) ? acc : lit;
+  }
+  return ok;
+}
+
 // dipole of one monomer: inc/dipole_response.jl:7-11 (dielectric), :27-29 with M = mu*I (polar)
 template <typename R, int CT>
 __device__ __forceinline__ void dipole(R a_or_mu, R k2e, R nx, R ny, R nz, R &mx, R &my, R &mz) {
