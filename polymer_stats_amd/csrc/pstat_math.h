@@ -265,11 +265,48 @@ __device__ __forceinline__ void sincos_f64(double x, double *s, double *c) {
   *c = ((q + 1) & 2) ? -ca : ca;
 }
 
+// sin and cos of a double for the HOT LOOP of the f64 sweep: ~30 instructions instead of ~50, each result within
+// 1.5 ulp (tools/mathcheck).  What is dropped against sincos_f64 is the low word of the reduced argument (r is carried
+// as one double, itself correctly rounded: k HI is exact inside the first fma) and fdlibm's compensated final sums
+// (plain Horner forms in fused multiply-adds).  Nothing here can move a chain off the oracle's trajectory: angles are
+// stored and proposed without any trigonometry, and sin/cos only enter the energy difference and the Jacobian
+// ratio of the Metropolis test, where a relative 1e-16 flips a decision with probability ~1e-16 per step; the
+// running observables agree with the oracle's to ~1e-15 relative instead of bit for bit.
+// BOUNDED: the caller guarantees 0 <= x <= pi (theta after the clamp), no huge-argument fold is compiled in.
+// sin(0) = 0, sin(fl(pi)) = 1.2246e-16 and cos(fl(pi/2)) = 6.1e-17 exactly as sincos_f64 gives them.
+template <bool BOUNDED>
+__device__ __forceinline__ void sincos_fast_f64(double x, double *s, double *c) {
+  if constexpr (!BOUNDED) {
+    if (!(fabs(x) < 1.0e5)) {   // fold by whole turns: 2 pi = HI2 + LO2
+      const double t = rint(x * 1.59154943091895345609e-01);
+      x = __builtin_fma(-t, 2.44929359829470641435e-16, __builtin_fma(-t, 6.28318530717958623200e+00, x));
+    }
+  }
+  const double k = rint(x * 6.36619772367581382433e-01);                  // x * 2/pi
+  const double r = __builtin_fma(-k, 6.12323399573676603587e-17, __builtin_fma(-k, 1.57079632679489655800e+00, x));
+  const double z = r * r;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2), S1);
+  const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+  const double ks = __builtin_fma(r * z, ps, r);
+  const double kc = __builtin_fma(z, __builtin_fma(z, pc, -0.5), 1.0);
+  const int q = (int)k;
+  const double sa = (q & 1) ? kc : ks, ca = (q & 1) ? ks : kc;
+  *s = (q & 2) ? -sa : sa;
+  *c = ((q + 1) & 2) ? -ca : ca;
+}
+
 template <typename R> struct Ang;
 template <> struct Ang<double> {
   static constexpr double theta_max = 3.14159265358979323846;
   static constexpr double unit = 1.0;  // radians per stored unit
   static __device__ __forceinline__ void sc(double x, double *s, double *c) { sincos_f64(x, s, c); }
+  // the sweep's hot loop (see sincos_fast_f64): theta is clamped to [0, pi], phi random-walks
+  static __device__ __forceinline__ void sc_theta(double x, double *s, double *c) { sincos_fast_f64<true>(x, s, c); }
+  static __device__ __forceinline__ void sc_phi(double x, double *s, double *c) { sincos_fast_f64<false>(x, s, c); }
   static __device__ __forceinline__ double wrap(double x) { return x; }  // phi random-walks, eap_chain.jl:232
 };
 template <> struct Ang<float> {
@@ -279,6 +316,8 @@ template <> struct Ang<float> {
     *s = __builtin_amdgcn_sinf(x);   // v_sin_f32 / v_cos_f32 take turns
     *c = __builtin_amdgcn_cosf(x);
   }
+  static __device__ __forceinline__ void sc_theta(float x, float *s, float *c) { sc(x, s, c); }
+  static __device__ __forceinline__ void sc_phi(float x, float *s, float *c) { sc(x, s, c); }
   static __device__ __forceinline__ float wrap(float x) { return __builtin_amdgcn_fractf(x); }
 };
 
