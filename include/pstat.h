@@ -51,8 +51,12 @@ enum { PSTAT_NONINTERACTING = 0, PSTAT_INTERACTING = 1, PSTAT_ISING = 2,
         * functor returns that sum ALONE -- with this energy neither the field nor the force enters U. */
        PSTAT_CUTOFF = 3 };
 /* arithmetic of the device path:
- *   PSTAT_F32  f32 state and transcendentals, f64 running sums (default);
- *   PSTAT_F64  f64 throughout (the reference's Float64; bit-reproduces the CPU oracle's trajectory);
+ *   PSTAT_F64  f64 throughout: the reference's Float64 (inc/types.jl:1-4), and the default.  Reproduces the CPU oracle's
+ *              (phi, theta) trajectory, generator state and counters bit for bit; observables to ~1e-15 relative.
+ *   PSTAT_F32  opt-in fast path: f32 state and transcendentals, f64 running sums.  Bias of the pooled averages of the
+ *              non-interacting energies <= 5e-6 relative.  NOT equivalent to f64 once chains
+ *              have collapsed into 1/r^3 contacts (|U| >~ 1e4 kT; interacting/Ising/cutoff energies at strong coupling):
+ *              kT-level fidelity there needs position differences good to ~1e-10 b (profiles/r02/config4_f32_vs_f64.json).
  *   PSTAT_Q16  opt-in: both angles live on a 2^16-point midpoint lattice (4 bytes of state per
  *              monomer, twice the chains resident per CU), f32 arithmetic, f64 running sums.
  *              Discretisation bias of ensemble averages: O(h^2) ~ 1e-10. */

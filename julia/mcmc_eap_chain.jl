@@ -90,7 +90,7 @@ s = ArgParseSettings();
   "--num-chains";          arg_type = Int;     default = 4096
   "--seed";                arg_type = Int;     default = -1;  help = "seed of the per-chain generators; default (-1): fresh OS entropy per run, like the reference's unseeded RNG"
   "--devices";             arg_type = String;  default = "0"
-  "--precision";           arg_type = String;  default = "f32"
+  "--precision";           arg_type = String;  default = "f64";  help = "device arithmetic: f64 (the reference's Float64) | f32 (fast path) | q16"
   "--rng";                 arg_type = String;  default = "mwc64x"
   "--burn-in";             arg_type = Int;     default = 0
   "--burn-schedule";       arg_type = String;  default = "[1]"

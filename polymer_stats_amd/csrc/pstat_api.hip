@@ -233,7 +233,7 @@ void pstat_default_params(pstat_params *p) {
   p->seed = 0; p->chain_id0 = 0;
   p->chain_type = PSTAT_DIELECTRIC; p->energy_type = PSTAT_NONINTERACTING;
   p->do_flips = 0; p->umbrella = 0;
-  p->precision = PSTAT_F32; p->device = 0;
+  p->precision = PSTAT_F64; p->device = 0;   // the reference's Float64 (inc/types.jl); PSTAT_F32 is the opt-in fast path
   p->rng = PSTAT_RNG_MWC64X; p->reserved = 0;
   // mcmc_clustering_eap_chain.jl:36-43,87-90,142-148 (only read when move_set = PSTAT_MOVES_CLUSTER / use_x0)
   p->move_set = PSTAT_MOVES_SINGLE;

@@ -220,7 +220,9 @@ __global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? 2 : (M == 2 ? PSTAT_
       R flip = 0;
       if (do_flips && (g.next() >> 31)) flip = AG::theta_max - 2 * th0;
       const R dth = flip + thstep * sym11<R>(g.next());
-      const R eps = u01<R>(g.next());
+      const uint32_t weps = g.next();
+      const R eps = u01<R>(weps);
+      (void)eps;
       const R st0 = at_idx(st, owner, slot);
       const R n0x = at_idx(nx, owner, slot), n0y = at_idx(ny, owner, slot), n0z = at_idx(nz, owner, slot);
       const R m0x = at_idx(mx, owner, slot), m0y = at_idx(my, owner, slot), m0z = at_idx(mz, owner, slot);
@@ -257,8 +259,7 @@ __global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? 2 : (M == 2 ? PSTAT_
       bool ok;
       const R dw = du * wscale;   // change of the umbrella weight function (0 if off)
       if constexpr (sizeof(R) == 8) {
-        const R dlt = -dU / kT + log_r(st1 / st0) + dw - lag;
-        ok = (dlt >= 0) || (eps < exp_r(dlt));
+        ok = metropolis_f64(dU, kT, -1.0 / kT, st1, st0, dw - lag, weps);
       } else {
         const R e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lag) + dU * nbeta_log2e);
         ok = eps * st0 < st1 * e;

@@ -76,7 +76,9 @@ def build_parser() -> argparse.ArgumentParser:
            "(the seed drawn is echoed on stderr at --verbose >= 2)")
     a("--devices", dest="devices", type=str, default="0", help="comma-separated HIP device ordinals; chains are sharded over them")
     a("--rng", dest="rng", type=str, default="mwc64x", help="per-chain generator: mwc64x | xoshiro128++")
-    a("--precision", dest="precision", type=str, default="f32", help="device arithmetic: f32 (f64 running sums) | f64")
+    a("--precision", dest="precision", type=str, default="f64",
+      help="device arithmetic: f64 (the reference's Float64; default) | f32 (fast path: f32 state, f64 running sums; not for collapsed "
+           "chains of the pair energies) | q16 (lattice angles, f32 arithmetic)")
     return p
 
 

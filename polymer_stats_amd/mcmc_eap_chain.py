@@ -85,7 +85,9 @@ def build_parser() -> argparse.ArgumentParser:
     a("--burn-schedule", dest="burn-schedule", type=str, default="[1]",
       help="kT multipliers of the burn-in ladder, e.g. '[1000; 100; 10; 2; 1]' (mcmc_clustering_eap_chain.jl:138-141)")
     a("--rng", dest="rng", type=str, default="mwc64x", help="per-chain generator: mwc64x | xoshiro128++")
-    a("--precision", dest="precision", type=str, default="f32", help="device arithmetic: f32 (f64 running sums) | f64 | q16 (lattice angles, f32 arithmetic)")
+    a("--precision", dest="precision", type=str, default="f64",
+      help="device arithmetic: f64 (the reference's Float64; default) | f32 (fast path: f32 state, f64 running sums; not for collapsed "
+           "chains of the pair energies) | q16 (lattice angles, f32 arithmetic)")
     return p
 
 

@@ -60,7 +60,7 @@ def test_defaults_are_the_references(ps):
     assert p.phi_step == 3 * math.pi / 8 and p.theta_step == 3 * math.pi / 16
     assert (p.adj_lb, p.adj_ub, p.adj_scale, p.steps_per_adjust) == (0.15, 0.55, 1.1, 2500)
     assert p.n == 100 and p.chain_type == ps.DIELECTRIC and p.energy_type == ps.NONINTERACTING
-    assert p.rng == ps.RNG_MWC64X and p.precision == ps.F32 and p.reserved == 0
+    assert p.rng == ps.RNG_MWC64X and p.precision == ps.F64 and p.reserved == 0      # Float64 like the reference
     # mcmc_clustering_eap_chain.jl:36-43,87-90,146-148
     assert p.move_set == ps.MOVES_SINGLE and (p.bend_mod, p.bend_angle, p.cluster_prob) == (0.0, 0.0, 0.5)
     assert p.use_x0 == 0 and (p.dx0_phi, p.dx0_theta) == (2 * math.pi, 0.1) and p.cutoff_radius == 7.5
