@@ -147,16 +147,16 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
   // (returns whether theta sits exactly on a clamp value, see `edge` below)
   auto nm_of = [&](const R2 a, T3 &nh, T3 &mu) __attribute__((always_inline)) -> bool {
     R s, co, sp, cp;
-    AG::sc(a.x, &s, &co);
-    AG::sc(a.y, &sp, &cp);
+    AG::sc_theta(a.x, &s, &co);
+    AG::sc_phi(a.y, &sp, &cp);
     nh.x = cp * s; nh.y = sp * s; nh.z = co;
     dipole<R, CT>(a_or_mu, k2e, nh.x, nh.y, nh.z, mu.x, mu.y, mu.z);
     return a.x == (R)0 || a.x == AG::theta_max;
   };
   auto nhat_of = [&](const R2 a, T3 &nh) __attribute__((always_inline)) -> bool {
     R s, co, sp, cp;
-    AG::sc(a.x, &s, &co);
-    AG::sc(a.y, &sp, &cp);
+    AG::sc_theta(a.x, &s, &co);
+    AG::sc_phi(a.y, &sp, &cp);
     nh.x = cp * s; nh.y = sp * s; nh.z = co;
     return a.x == (R)0 || a.x == AG::theta_max;
   };
@@ -250,10 +250,10 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
         th1 = fmin(AG::theta_max, fmax((R)0, th0 + thstep * sym11<R>(wth)));
       }
       R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
-      AG::sc(th0, &st0, &ct0);
-      AG::sc(th1, &st1, &ct1);
-      AG::sc(ph0, &sp0, &cp0);
-      AG::sc(ph1, &sp1, &cp1);
+      AG::sc_theta(th0, &st0, &ct0);
+      AG::sc_theta(th1, &st1, &ct1);
+      AG::sc_phi(ph0, &sp0, &cp0);
+      AG::sc_phi(ph1, &sp1, &cp1);
       const T3 n0{cp0 * st0, sp0 * st0, ct0}, n1{cp1 * st1, sp1 * st1, ct1};
       T3 m0, m1;
       dipole<R, CT>(a_or_mu, k2e, n0.x, n0.y, n0.z, m0.x, m0.y, m0.z);
@@ -400,9 +400,12 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
       bool ok;
       const R dw = umb ? dus * wscale : (R)0;
       if constexpr (sizeof(R) == 8) {
-        const R delta = -dU / kT + log_r(st1 / st0) + dw + log_r(alpha) - lag;
-        const R eps = u01<R>(weps);
-        ok = (delta >= 0) || (eps < exp_r(delta));
+        // (the f32 filter of pstat_math.h decides all but ~1e-5 of the draws; the literal expression the rest)
+        ok = metropolis_filter(dU * (-1.0 / kT) + (dw - lag), st1 * alpha, st0, weps, [&]() -> bool {
+          const R delta = -dU / kT + log_r(st1 / st0) + dw + log_r(alpha) - lag;
+          const R eps = u01<R>(weps);
+          return (delta >= 0) || (eps < exp_r(delta));
+        });
       } else {
         const R e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lag) + dU * nbeta_log2e) * alpha;
         ok = bits12(weps) * st0 < fma_r(st1, e, st0);   // (1 + u) sin0 < sin1 e alpha + sin0

@@ -105,21 +105,30 @@ __device__ __forceinline__ R sym11(uint32_t w) {  // 2u - 1 in [-1,1)
 // verdict is then taken unchanged.  The decision is therefore ALWAYS the literal one (the bit-parity tests against
 // the oracle hold); the filter only spares its evaluation.  NaN, +-inf, underflow to 0 and eps = 0 all land in the
 // literal branch or on the side the literal test takes.
-__device__ __forceinline__ bool metropolis_f64(const double dU, const double kT, const double ninv_kT, const double st1,
-                                               const double st0, const double extra, const uint32_t weps) {
-  const float t = (float)(dU * ninv_kT + extra);
+// x = everything in delta except the logarithm of the ratio num / den (sweep: num / den = sin(theta') / sin(theta); clustering
+// main: times the Hastings ratio alpha); literal() = the reference's expression, evaluated only in the rare branch.
+template <typename Literal>
+__device__ __forceinline__ bool metropolis_filter(const double x, const double num, const double den, const uint32_t weps,
+                                                  Literal &&literal) {
+  const float t = (float)x;
   const float e = __builtin_amdgcn_exp2f(t * 1.44269504f);
-  const float lhs = (__uint_as_float(0x3F800000u | (weps >> 9)) - 1.0f) * (float)st0, rhs = e * (float)st1;
+  const float lhs = (__uint_as_float(0x3F800000u | (weps >> 9)) - 1.0f) * (float)den, rhs = e * (float)num;
   const float m = 2e-6f + 1e-6f * __builtin_fabsf(t);          // > 3x the f32 error of rhs / lhs
   const bool acc = __builtin_fmaf(lhs, m, lhs) < rhs, rej = lhs > __builtin_fmaf(rhs, m, rhs);
   bool ok = acc;
   if (__builtin_amdgcn_ballot_w64(!(acc || rej)) != 0) {        // some lane is too close to call (or not finite)
-    const double delta = -dU / kT + log_f64(st1 / st0) + extra;
-    const double eps = (double)(weps >> 9) * (1.0 / 8388608.0);
-    const bool lit = (delta >= 0) || (eps < exp_f64(delta));
+    const bool lit = literal();
     ok = (acc || rej) ? acc : lit;
   }
   return ok;
+}
+__device__ __forceinline__ bool metropolis_f64(const double dU, const double kT, const double ninv_kT, const double st1,
+                                               const double st0, const double extra, const uint32_t weps) {
+  return metropolis_filter(dU * ninv_kT + extra, st1, st0, weps, [&]() -> bool {
+    const double delta = -dU / kT + log_f64(st1 / st0) + extra;
+    const double eps = (double)(weps >> 9) * (1.0 / 8388608.0);
+    return (delta >= 0) || (eps < exp_f64(delta));
+  });
 }
 
 // dipole of one monomer: inc/dipole_response.jl:7-11 (dielectric), :27-29 with M = mu*I (polar)
@@ -165,7 +174,19 @@ __device__ __forceinline__ float pair_term_fast(float rx, float ry, float rz, fl
 }
 __device__ __forceinline__ double pair_term_fast(double rx, double ry, double rz, double mix, double miy,
                                                  double miz, double mjx, double mjy, double mjz) {
-  return pair_term<double>(rx, ry, rz, mix, miy, miz, mjx, mjy, mjz);   // f64: the literal form
+  // f64 hot loops: the same algebraic form as the f32 one, 1/r from v_rsq_f64 and two Newton steps (full double
+  // precision; ~30 instructions against ~75 for the literal sqrt + divisions of pair_term<double>, which the
+  // initialisation kernels keep).  r = 0 gives NaN, as the literal form does.
+  const double r2 = __builtin_fma(rz, rz, __builtin_fma(ry, ry, rx * rx));
+  double y = __builtin_amdgcn_rsq(r2);
+  y = __builtin_fma(0.5 * y, __builtin_fma(-r2 * y, y, 1.0), y);
+  y = __builtin_fma(0.5 * y, __builtin_fma(-r2 * y, y, 1.0), y);
+  const double ir2 = y * y;
+  const double mimj = __builtin_fma(miz, mjz, __builtin_fma(miy, mjy, mix * mjx));
+  const double mir = __builtin_fma(miz, rz, __builtin_fma(miy, ry, mix * rx));
+  const double mjr = __builtin_fma(mjz, rz, __builtin_fma(mjy, ry, mjx * rx));
+  const double num = __builtin_fma(-3.0 * ir2, mir * mjr, mimj);
+  return num * (ir2 * y) * 0.0795774715459476679;   // 1/(4 pi)
 }
 
 template <typename T> __device__ __forceinline__ T store_phi(double u) {   // phi ~ U(0, 2pi), u in [0,1)
