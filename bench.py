@@ -21,10 +21,13 @@ in the same run with the same K/W and reported in the sibling object `fast_path`
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (32 B per attempted update in f64: one
 (theta, phi) pair read and written; 16 B in f32 -- SURVEY.md 8(d)) x updates per launch / mean launch time
-measured with HIP events on the launch stream.  The path keeps its state on chip, so that figure is an
-EQUIVALENT rate; what bounds the kernel is VALU issue (`valu`), and `lds` is the third fraction SURVEY 8(d)
-asks for.  `traffic` / `valu.ops_per_update` come from the PMC passes in profiles/pmc_traffic.json and are used
-only if that file was collected on the kernel sources being benchmarked (sha256 stamp), else null / estimate.
+measured with HIP events on the launch stream.  The f64 kernel at n = 100 keeps 39 of the 100 monomers' cells in LDS
+and the rest in memory (L2 / Infinity Cache), so its `traffic` is real fabric traffic -- about 1.7x
+the algorithmic bytes, the price of 16-byte random accesses at 64-byte granularity; the f32 kernel keeps all state in
+LDS, its figure is an EQUIVALENT rate (`equivalent: true`) and its traffic is ~1 % of it.  Both kernels are bound by
+VALU issue (`valu`); `lds` is the third fraction SURVEY 8(d) asks for.  `traffic` / `valu.ops_per_update` come from
+the PMC passes in profiles/pmc_traffic.json and are used only if that file was collected on the kernel sources being
+benchmarked (sha256 stamp), else null / estimate.
 """
 from __future__ import annotations
 
@@ -45,7 +48,7 @@ FZ_SWEEP = [round(0.05 * i, 2) for i in range(21)] + [1.5 + 0.5 * i for i in ran
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz = 7.86e13 f32 lane-ops/s (f64: half of it)
 LDS_PEAK_GBS = 256 * 256 * 2.4              # CUs x 256 B/clk (MI355X_MICROARCH.md, LDS) x GHz = 157 TB/s
-VALU_OPS_ESTIMATE = {"f32": 220, "f64": 590, "q16": 220}   # SURVEY.md 8(d) / DESIGN 3.1; replaced by the PMC count when valid
+VALU_OPS_ESTIMATE = {"f32": 85, "f64": 280, "q16": 85}   # last PMC counts (profiles/r02); replaced by the stamped record when valid
 STATE_BYTES = {"f32": 16, "f64": 32, "q16": 8}              # one state cell read + written per attempted update
 DTYPE = {"f32": "f32 state+transcendentals, f64 running sums", "f64": "f64",
          "q16": "u16 lattice angles, f32 transcendentals, f64 running sums"}
@@ -298,6 +301,9 @@ def main():
                 src = "SQ_INSTS_VALU x 64 / updates, profiles/pmc_traffic.json (stamp = sha256 of the kernel sources)"
         valu_peak = VALU_LANE_OPS_PEAK * (0.5 if precision == "f64" else 1.0)   # v_fma_f64: 16 lanes/clk/SIMD
         last, info = rec["last"], rec["info"]
+        in_memory = "state in L2" in info.kernel.decode()
+        # state in memory: (LDS bytes / 1 KiB per row of 64 lanes x 16 B) - 1 trash row = monomers whose cells are in LDS
+        lds_share = min(1.0, (info.lds_bytes // 1024 - 1) / args.n) if in_memory else 1.0
         return {
             "value": world * upd_per_launch * args.steps / rec["elapsed"],
             "ms_per_step": rec["elapsed"] / args.steps * 1e3,
@@ -306,16 +312,19 @@ def main():
             "workgroups": int(info.blocks), "wg_per_cu_resident": info.blocks_per_cu,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": mean_ms,
-                         "equivalent": True,
-                         "note": "algorithmic bytes = %d B/update x %d updates per launch / HIP-event kernel time; state is "
-                                 "on-chip resident, so this is an equivalent rate, not HBM traffic (see `traffic`); the "
-                                 "kernel's real bound is `valu`" % (STATE_BYTES[precision], upd_per_launch)},
+                         "equivalent": not in_memory,
+                         "note": ("algorithmic bytes = %d B/update x %d updates per launch / HIP-event kernel time; " % (STATE_BYTES[precision], upd_per_launch)) +
+                                 ("part of the state lives in memory (L2 / Infinity Cache): `traffic` is what the fabric carried; "
+                                  "the kernel's bound is `valu`" if in_memory else
+                                  "state is on-chip resident, so this is an equivalent rate, not HBM traffic (see `traffic`); "
+                                  "the kernel's real bound is `valu`")},
             "valu": {"bound": "valu-issue", "achieved": rate * valu_ops / 1e12, "peak": valu_peak / 1e12,
                      "unit": "T lane-ops/s", "frac": rate * valu_ops / valu_peak,
                      "ops_per_update": valu_ops, "ops_source": src},
-            "lds": {"bound": "lds-bandwidth", "achieved": STATE_BYTES[precision] * rate / 1e9, "peak": LDS_PEAK_GBS,
-                    "unit": "GB/s", "frac": STATE_BYTES[precision] * rate / 1e9 / LDS_PEAK_GBS,
-                    "note": "one state cell read + one written per update (ds_read/ds_write of %d B)" % (STATE_BYTES[precision] // 2)},
+            "lds": {"bound": "lds-bandwidth", "achieved": lds_share * STATE_BYTES[precision] * rate / 1e9, "peak": LDS_PEAK_GBS,
+                    "unit": "GB/s", "frac": lds_share * STATE_BYTES[precision] * rate / 1e9 / LDS_PEAK_GBS,
+                    "note": "one state cell read + one written per update (ds_read/ds_write of %d B)%s" %
+                            (STATE_BYTES[precision] // 2, "; %.0f %% of the cells live in LDS" % (100 * lds_share) if in_memory else "")},
             "check": {"Fz": FZ_SWEEP[(nstep_total - 1) % len(FZ_SWEEP)], "r3": last.avg[2], "r3_stderr": last.stderr[2],
                       "p3": last.avg[9], "U": last.avg[14], "AR": last.acceptance_ratio,
                       "chains_pooled": int(last.num_chains), "nan_rejects": int(last.nan_rejects),

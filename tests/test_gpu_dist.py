@@ -1,5 +1,5 @@
 """N > 1 on the GPU box: two processes (gloo, both on device 0) each own a shard of the chains by global
-chain id, advance it with libpstat, reduce on the device and merge with ONE all-reduce(SUM) of the 39-double
+chain id, advance it with libpstat, reduce on the device and merge with ONE all-reduce(SUM) of the 41-double
 vector -- the data path of bench.py --gpus N with gloo standing in for RCCL.  The merged summary must equal
 the one of a single handle holding all chains (chains are identified by id, not by owner)."""
 import os
@@ -54,3 +54,26 @@ def test_two_ranks_on_one_gpu_merge_to_the_single_handle_result(tmp_path, moves)
     np.testing.assert_allclose(np.array(merged.stderr), np.array(single.stderr), rtol=1e-7, atol=1e-12)
     np.testing.assert_allclose(np.array(merged.extra_avg), np.array(single.extra_avg), rtol=1e-11, atol=1e-12)
     assert merged.acceptance_ratio == pytest.approx(single.acceptance_ratio, rel=1e-12)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a bare shell (no torchrun, WORLD_SIZE unset): the parent never touches the GPU, starts
+    two fresh rank processes (here both on device 0, gloo standing in for RCCL), relays rank 0's single JSON line and
+    exits 0; the line pools both ranks' chains.  A failing rank must fail the whole command."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--chains", "4096", "--mc-steps", "3000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["steps"] == 2
+    assert d["check"]["chains_pooled"] == 2 * 4096
+    assert d["value"] == pytest.approx(2 * 4096 * 3000 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)
+    assert d["fast_path"]["dtype"].startswith("f32") and d["fast_path"]["check"]["chains_pooled"] == 2 * 4096
+    assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
+    bad = subprocess.run(cmd + ["--precision", "nonsense"], env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and bad.stdout.strip() == ""
