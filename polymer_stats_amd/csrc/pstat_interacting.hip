@@ -50,7 +50,10 @@ template <typename R, typename G, int CT, int M>
 #ifndef PSTAT_IOCC_F64M2
 #define PSTAT_IOCC_F64M2 2
 #endif
-__global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? 2 : (M == 2 ? PSTAT_IOCC_F64M2 : 1))
+#ifndef PSTAT_IOCC_F64M1
+#define PSTAT_IOCC_F64M1 3   // (measured round 2, n = 64: 2 waves 3.47e8, 3 waves see DESIGN, 4 waves 2.68e8 -- spills)
+#endif
+__global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? PSTAT_IOCC_F64M1 : (M == 2 ? PSTAT_IOCC_F64M2 : 1))
                                                 : (M == 1 ? PSTAT_IOCC_M1 : (M == 2 ? PSTAT_IOCC_M2 : PSTAT_IOCC_M4))) void interacting_kernel(SweepArgs A, DevState S,
                                                          const CaseConst *__restrict__ cases,
                                                          int do_flips, int use_lag, int umb,

@@ -111,7 +111,17 @@ __device__ __forceinline__ R ring_pair_sum(R4 *ringA, R2 *ringB_, const int lane
     vb[j].x = tmy[j]; vb[j].y = tmz[j];
     if constexpr (sizeof(R) == 4) { vb[j].z = tmy[j]; vb[j].w = tmz[j]; }   // both halves are read: see accum
     if (in_ring) {
-      ringA[lane * M + j] = va[j]; ringA[(lane + L) * M + j] = va[j];
+      if constexpr (sizeof(R) == 8) {
+        // f64: a double4 entry would be read as two ds_read_b128 at a 32-byte lane stride -- two-way bank conflicts on
+        // every read (measured: 38 % of the LDS-active cycles of the f64 interacting kernel).  (x, y) and (z, mu_x)
+        // therefore live in two separate arrays of 16-byte entries, like (mu_y, mu_z).
+        R2 *rxy = reinterpret_cast<R2 *>(ringA), *rzm = rxy + 128 * M;
+        const R2 xy = {va[j].x, va[j].y}, zm = {va[j].z, va[j].w};
+        rxy[lane * M + j] = xy; rxy[(lane + L) * M + j] = xy;
+        rzm[lane * M + j] = zm; rzm[(lane + L) * M + j] = zm;
+      } else {
+        ringA[lane * M + j] = va[j]; ringA[(lane + L) * M + j] = va[j];
+      }
       ringB[lane * M + j] = vb[j]; ringB[(lane + L) * M + j] = vb[j];
     }
   }
@@ -156,7 +166,14 @@ __device__ __forceinline__ R ring_pair_sum(R4 *ringA, R2 *ringB_, const int lane
     R t = 0;
 #pragma unroll
     for (int jp = 0; jp < M; ++jp) {
-      const R4 qa = pa[(L - k) * M + jp];
+      R4 qa;
+      if constexpr (sizeof(R) == 8) {
+        const R2 *rxy = reinterpret_cast<const R2 *>(ringA) + me * M, *rzm = rxy + 128 * M;
+        const R2 xy = rxy[(L - k) * M + jp], zm = rzm[(L - k) * M + jp];
+        qa.x = xy.x; qa.y = xy.y; qa.z = zm.x; qa.w = zm.y;
+      } else {
+        qa = pa[(L - k) * M + jp];
+      }
       const RB qb = pb[(L - k) * M + jp];
 #pragma unroll
       for (int j = 0; j < M; ++j) accum(t, j, qa, qb);
