@@ -157,7 +157,11 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   constexpr bool Q = ST == 1;
   constexpr bool GM = ST == 2;
   static_assert(!Q || sizeof(R) == 4, "the lattice state runs on f32 arithmetic");
-  static_assert(!GM || (sizeof(R) == 8 && EN == PSTAT_NONINTERACTING), "global-memory state: f64, non-interacting");
+  static_assert(!GM || sizeof(R) == 8, "global-memory state: f64");
+  // GM pipeline depth: 2 steps for the non-interacting step; the Ising step is ~2.5x as long and fetches three rows (the
+  // monomer and its two neighbours), so one step ahead gives its loads the same time and a third of the registers
+  constexpr bool GI = GM && EN == PSTAT_ISING;
+  constexpr int DEPTH = GI ? 1 : 2;
   using Cell = typename std::conditional<Q, uint32_t, R2>::type;
   const int lanes = GM ? 64 : A.lanes;
   unsigned char *const cells = GM ? reinterpret_cast<unsigned char *>(S.work) + (size_t)blk * (size_t)A.n * 64 * sizeof(Cell) : smem;
@@ -243,18 +247,50 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // row.  A rejected step is steered away on both sides, so it stores nothing.
   typedef int v4i __attribute__((ext_vector_type(4)));
   struct RowG { Cell l; v4i g; };
-  using Row = typename std::conditional<GM, RowG, Cell>::type;
+  struct RowG3 { RowG c, lo, hi; };     // Ising: the monomer, its lower and its upper neighbour
+  using Row = typename std::conditional<GI, RowG3, typename std::conditional<GM, RowG, Cell>::type>::type;
   const uint32_t nL = GM ? (uint32_t)A.lds_rows : 0u;
   const uint32_t trash = nL * row_bytes + lane_bytes;        // LDS row nL: never read for its contents
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(GM ? (void *)cells : (void *)nullptr, 0,
                                                                   GM ? (int)((uint32_t)n * row_bytes) : 0, 0x00020000);
-  auto rdrow = [&](const Draw &d) __attribute__((always_inline)) -> Row {
+  auto rdcell = [&](const uint32_t idx, const uint32_t cell) __attribute__((always_inline)) -> RowG {
+    const bool inL = idx < nL;
+    RowG r;
+    r.l = *reinterpret_cast<Cell *>(smem + (inL ? cell : trash));
+    r.g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, inL ? 0xFFFFFFFFu : cell, 0, 0);
+    return r;
+  };
+  // a fetched cell at its first use: its home, then the commits made after its load was issued (fw2 older, fw1 newer)
+  auto resolve = [&](const RowG &r, const uint32_t idx, const uint32_t cell, const Cell &f1, const uint32_t at1,
+                     const Cell &f2, const uint32_t at2) __attribute__((always_inline)) -> Cell {
     if constexpr (GM) {
-      const bool inL = d.idx < nL;
-      RowG r;
-      r.l = *reinterpret_cast<Cell *>(smem + (inL ? d.cell : trash));
-      r.g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, inL ? 0xFFFFFFFFu : d.cell, 0, 0);
+      typedef double v2dd __attribute__((ext_vector_type(2)));
+      const v2dd gv = __builtin_bit_cast(v2dd, r.g);
+      const bool inL = idx < nL;
+      Cell a;
+      a.x = inL ? r.l.x : gv.x; a.y = inL ? r.l.y : gv.y;
+      if constexpr (DEPTH == 2) {
+        const bool s2 = at2 == cell;
+        a.x = s2 ? f2.x : a.x; a.y = s2 ? f2.y : a.y;
+      }
+      const bool s1 = at1 == cell;
+      a.x = s1 ? f1.x : a.x; a.y = s1 ? f1.y : a.y;
+      return a;
+    } else {
+      return r.l;
+    }
+  };
+  auto rdrow = [&](const Draw &d) __attribute__((always_inline)) -> Row {
+    if constexpr (GI) {
+      // at a chain end the missing neighbour's slot re-reads the monomer itself; its bond is masked out in the step
+      const bool hasLo = d.idx > 0, hasHi = d.idx + 1 < (uint32_t)n;
+      RowG3 r;
+      r.c = rdcell(d.idx, d.cell);
+      r.lo = rdcell(hasLo ? d.idx - 1 : d.idx, hasLo ? d.cell - row_bytes : d.cell);
+      r.hi = rdcell(hasHi ? d.idx + 1 : d.idx, hasHi ? d.cell + row_bytes : d.cell);
       return r;
+    } else if constexpr (GM) {
+      return rdcell(d.idx, d.cell);
     } else {
       return slot(d.cell);
     }
@@ -282,7 +318,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   Cell fw1_cell{}, fw2_cell{};
   uint32_t fw1_at = ~0u, fw2_at = ~0u;
   (void)dC; (void)aC; (void)fw1_cell; (void)fw2_cell; (void)fw1_at; (void)fw2_at;
-  if constexpr (GM) {
+  if constexpr (GM && DEPTH == 2) {
     if (remaining > 1) {
       dB = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes);
       aB = rdrow(dB);
@@ -351,15 +387,15 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     // one Monte-Carlo step on (d, a0); fetches the next step's draws and LDS row into (dn, an)
     auto one_step = [&](const Draw &d, const Row &a0_, Draw &dn, Row &an, const bool more)
         __attribute__((always_inline)) {
-      Cell a0;
-      if constexpr (GM) {   // the row's home, then the two preceding commits forwarded into it, the older one first
-        typedef double v2dd __attribute__((ext_vector_type(2)));
-        const v2dd gv = __builtin_bit_cast(v2dd, a0_.g);
-        const bool inL = d.idx < nL;
-        a0.x = inL ? a0_.l.x : gv.x; a0.y = inL ? a0_.l.y : gv.y;
-        const bool s2 = fw2_at == d.cell, s1 = fw1_at == d.cell;
-        a0.x = s2 ? fw2_cell.x : a0.x; a0.y = s2 ? fw2_cell.y : a0.y;
-        a0.x = s1 ? fw1_cell.x : a0.x; a0.y = s1 ? fw1_cell.y : a0.y;
+      Cell a0, aLo{}, aHi{};      // (aLo, aHi: Ising with cells in memory -- the neighbours, fetched with the row)
+      (void)aLo; (void)aHi;
+      if constexpr (GI) {
+        const bool hasLo = d.idx > 0, hasHi = d.idx + 1 < (uint32_t)n;
+        a0 = resolve(a0_.c, d.idx, d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at);
+        aLo = resolve(a0_.lo, hasLo ? d.idx - 1 : d.idx, hasLo ? d.cell - row_bytes : d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at);
+        aHi = resolve(a0_.hi, hasHi ? d.idx + 1 : d.idx, hasHi ? d.cell + row_bytes : d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at);
+      } else if constexpr (GM) {
+        a0 = resolve(a0_, d.idx, d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at);
       } else {
         a0 = a0_;
       }
@@ -498,7 +534,26 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         D = Z1 - Z0;
 
         // ---- energy difference, inc/energy.jl:7-9,20-23; inc/eap_chain.jl:53
-        if constexpr (EN == PSTAT_ISING) {
+        if constexpr (GI) {
+          // cells in memory: the neighbours came with the row; branch-free, a missing neighbour's bond is masked out
+          R e0 = 0, e1 = 0;
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            const Cell aj = side ? aHi : aLo;
+            const bool has = side ? d.idx + 1 < (uint32_t)n : d.idx > 0;
+            R sj, cj, spj, cpj, mjx, mjy, mjz;
+            AG::sc_theta(aj.x, &sj, &cj);
+            AG::sc_phi(aj.y, &spj, &cpj);
+            const R njx = cpj * sj, njy = spj * sj, njz = cj;
+            dipole<R, CT>(a_or_mu, k2e, njx, njy, njz, mjx, mjy, mjz);
+            const R t0 = pair_term_fast(hb * (Nxy0.x + njx), hb * (Nxy0.y + njy), hb * (ct0 + njz),
+                                        Mxy0.x, Mxy0.y, mz0, mjx, mjy, mjz);
+            const R t1 = pair_term_fast(hb * (Nxy1.x + njx), hb * (Nxy1.y + njy), hb * (ct1 + njz),
+                                        Mxy1.x, Mxy1.y, mz1, mjx, mjy, mjz);
+            e0 += has ? t0 : (R)0; e1 += has ? t1 : (R)0;
+          }
+          dpair = e1 - e0;
+        } else if constexpr (EN == PSTAT_ISING) {
           R e0 = 0, e1 = 0;
   #pragma unroll
           for (int side = -1; side <= 1; side += 2) {
@@ -611,16 +666,28 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       // exactly how many younger operations are in flight, or it ends up waiting for the previous step's STORE as well.
       // The main loop therefore prefetches unconditionally and the segment's last steps run in the tail.
       // (`more` of a step = a step two after it exists in this segment; the main loop covers only such steps)
-      const int lim = chunk < left - 2 ? chunk : left - 2;
-      for (; k + 3 <= lim; k += 3) {
-        one_step(dA, aA, dC, aC, true);
-        one_step(dB, aB, dA, aA, true);
-        one_step(dC, aC, dB, aB, true);
-      }
-      for (; k < chunk; ++k) {
-        one_step(dA, aA, dC, aC, left - k > 2);
-        dA = dB; aA = aB;
-        dB = dC; aB = aC;
+      if constexpr (DEPTH == 2) {
+        const int lim = chunk < left - 2 ? chunk : left - 2;
+        for (; k + 3 <= lim; k += 3) {
+          one_step(dA, aA, dC, aC, true);
+          one_step(dB, aB, dA, aA, true);
+          one_step(dC, aC, dB, aB, true);
+        }
+        for (; k < chunk; ++k) {
+          one_step(dA, aA, dC, aC, left - k > 2);
+          dA = dB; aA = aB;
+          dB = dC; aB = aC;
+        }
+      } else {   // one step deep (Ising): two register sets
+        const int lim = chunk < left - 1 ? chunk : left - 1;
+        for (; k + 2 <= lim; k += 2) {
+          one_step(dA, aA, dB, aB, true);
+          one_step(dB, aB, dA, aA, true);
+        }
+        for (; k < chunk; ++k) {
+          one_step(dA, aA, dB, aB, left - k > 1);
+          dA = dB; aA = aB;
+        }
       }
     } else {
     for (; k + (UNROLL - 1) < chunk; k += UNROLL) {
@@ -897,12 +964,11 @@ using SweepFn = void (*)(SweepArgs, DevState, const CaseConst *, SweepRare, int 
 
 #ifdef PSTAT_PART
 // One object per state format: 1 = f32 (turns), 2 = q16 (lattice, f32 arithmetic), 3 = f64 with the cells in LDS,
-// 4 = f64 with the cells in global memory (non-interacting energy only).
+// 4 = f64 with the cells in global memory.
 template <typename G, int CT, int EN, bool FX, bool RARE>
 static SweepFn pick_state() {
 #if PSTAT_PART == 4
-  if constexpr (EN == PSTAT_NONINTERACTING) return sweep_kernel<double, G, CT, EN, FX, RARE, 2>;
-  else return nullptr;
+  return sweep_kernel<double, G, CT, EN, FX, RARE, 2>;
 #elif PSTAT_PART == 3
   return sweep_kernel<double, G, CT, EN, FX, RARE, 0>;
 #elif PSTAT_PART == 2
@@ -949,7 +1015,8 @@ SweepFn pick_sweep_f64g(const LaunchCfg &cfg);
 // (n > 40) the non-interacting f64 sweep keeps its cells in global memory instead and runs 64 lanes on every
 // SIMD (run_segment, ST = 2).  PSTAT_F64_STATE=lds|global overrides the choice (experiments, tests).
 bool f64_state_global(const LaunchCfg &cfg, int64_t n) {
-  if (cfg.precision != PSTAT_F64 || cfg.move_set != PSTAT_MOVES_SINGLE || cfg.energy_type != PSTAT_NONINTERACTING) return false;
+  if (cfg.precision != PSTAT_F64 || cfg.move_set != PSTAT_MOVES_SINGLE ||
+      (cfg.energy_type != PSTAT_NONINTERACTING && cfg.energy_type != PSTAT_ISING)) return false;
   const char *e = getenv("PSTAT_F64_STATE");
   if (e && e[0] == 'l') return false;
   if (e && e[0] == 'g') return true;

@@ -23,7 +23,10 @@ def ps():
     return ps
 
 
-def _bit_parity(ps, oracle, nsteps, nchains, **kw):
+def _bit_parity(ps, oracle, nsteps, nchains, obs_tol=(1e-9, 1e-9), **kw):
+    """Trajectory (angles, generator, counters, step sizes): bit for bit.  Observables: to `obs_tol` = (rtol, atol) -- the
+    kernels' energies are rounded differently from the oracle's literal ones in the last bits (fused multiply-adds, the
+    rsq-Newton pair term), and a running U that has passed through large Ising pair terms keeps their absolute rounding."""
     op, pp = both(nsteps, num_chains=nchains, precision=ps.F64, **kw)
     with ps.Ensemble(pp) as e:
         e.advance(nsteps)
@@ -38,7 +41,7 @@ def _bit_parity(ps, oracle, nsteps, nchains, **kw):
             assert g["nacc_total"] == o.nacc_total
             assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step
             np.testing.assert_allclose(g["sums"], o.sums, rtol=1e-9, atol=1e-7)
-            np.testing.assert_allclose(e.microstate(c), np.r_[o.r, o.p, o.U], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(e.microstate(c), np.r_[o.r, o.p, o.U], rtol=obs_tol[0], atol=obs_tol[1])
             nan_oracle += o.nan_rejects
         # proposals with a non-finite trial energy.  Not compared for equality: whether two monomers clamped onto the pole
         # (theta = 0 next to theta = fl(pi)) land on EXACTLY the same position, r = 0 => NaN, or 1e-16 apart => a finite
@@ -76,6 +79,9 @@ def test_f64_bit_parity_polar(ps, oracle):
 def test_f64_bit_parity_ising(ps, oracle):
     _bit_parity(ps, oracle, 4000, 64, n=24, E0=1.0, K1=1.0, Fz=0.25, energy_type=2, seed=9,
                 steps_per_adjust=400)
+    # n > 40: the cells live in LDS + memory and the neighbours are fetched with the row (run_segment, ST = 2)
+    _bit_parity(ps, oracle, 3000, 70, obs_tol=(1e-7, 1e-5), n=90, E0=1.0, K1=0.3, K2=0.05, Fz=0.25, Fx=0.1, energy_type=2,
+                seed=10, steps_per_adjust=400)
 
 
 @pytest.mark.parametrize("rng", [0, 1])
