@@ -198,12 +198,14 @@ def test_segments_checkpoint_and_sharding_invariance(ps, oracle):
         assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["phi"], b["phi"])
 
 
-@pytest.mark.parametrize("prec", [0, 2])
-def test_time_segments_match_single_launch(ps, monkeypatch, prec):
+@pytest.mark.parametrize("prec,n,et", [(0, 40, 0), (2, 40, 0), (1, 40, 0), (1, 60, 0), (1, 60, 2)],
+                         ids=["f32", "q16", "f64-lds", "f64-memory", "f64-memory-ising"])
+def test_time_segments_match_single_launch(ps, monkeypatch, prec, n, et):
     """The persistent sweep kernel splits a launch into (chain block, time segment) jobs.  With every
     job co-resident (64 blocks x 3 segments) later segments really wait on their predecessors; the
-    result must be bit-identical to the unsegmented launch."""
-    pp = ps.default_params(num_chains=4096, precision=prec, n=40, E0=1.0, Fz=0.5, seed=6)
+    result must be bit-identical to the unsegmented launch.  For the f64 kernel with its cells in memory a segment
+    boundary is also a spill of the working buffer to the checkpoint layout and a refill, possibly on another CU."""
+    pp = ps.default_params(num_chains=4096, precision=prec, n=n, E0=1.0, Fz=0.5, seed=6, energy_type=et, K1=0.3 if et else 1.0)
     monkeypatch.setenv("PSTAT_MAX_SPINS", str(1 << 19))     # fail within ~1 s instead of hanging
     states = {}
     for nseg in ("1", "3", "7"):

@@ -69,6 +69,10 @@ def main():
             res.append(run(ps, torch, f"C4 n=64 interacting dielectric E0=1 Fz=0.5 [{tag}]",
                            P(n=64, E0=1.0, K1=1.0, Fz=0.5, energy_type=ps.INTERACTING, num_chains=16384, precision=prec,
                              seed=4), 20000 // q))
+            for nn, st in ((100, 6000), (200, 2000)):       # the reference's interacting sweep sizes (run/interacting_*_study.jl)
+                res.append(run(ps, torch, f"C4b n={nn} interacting dielectric E0=1 Fz=0.5 [{tag}]",
+                               P(n=nn, E0=1.0, K1=1.0, Fz=0.5, energy_type=ps.INTERACTING, num_chains=16384, precision=prec,
+                                 seed=4), st // q))
         # C5: (E0, kT) phase grid of run/K1_E0-kT-phase.jl:21-24 (26 x 21 = 546 points), n = 200
         grid = [P(n=200, E0=0.2 * i, kT=10 ** (-2 + 0.2 * j), K1=1.0, num_chains=128, precision=prec, seed=1000 + 21 * i + j,
                   energy_type=et) for i in range(26) for j in range(21) for et in (ps.NONINTERACTING,)]
