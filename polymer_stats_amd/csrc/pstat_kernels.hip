@@ -608,7 +608,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       Cell a1;
       if constexpr (Q) a1 = ok ? cell1 : a0;
       else { a1.x = ok ? th1 : th0; a1.y = ok ? ph1 : ph0; }
-      wr(d, a1, ok);
+      if constexpr (GM) { Cell t1; t1.x = th1; t1.y = ph1; wr(d, t1, ok); }   // (steered away unless accepted)
+      else wr(d, a1, ok);
       const R m = ok ? (R)1 : (R)0;
       const P mm = {m, m};
       if constexpr (sizeof(R) == 8) {  // the oracle's update order: r += b*dn, p += dm, U += dU
@@ -628,8 +629,9 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       nacc_seg += ok ? 1 : 0;
       if constexpr (EN == PSTAT_ISING) nnan_seg += not_finite(dU) ? 1 : 0;
       if constexpr (GM) {
+        // (a rejected step changed nothing in memory: it forwards nothing, so the trial angles need no select here)
         fw2_cell = fw1_cell; fw2_at = fw1_at;
-        fw1_cell = a1; fw1_at = d.cell;
+        fw1_cell.x = th1; fw1_cell.y = ph1; fw1_at = ok ? d.cell : ~0u;
       } else if (more) {  // forward the accepted angles into the prefetched row if it is the same monomer
         const bool same = dn.cell == d.cell;
         if constexpr (Q) an = same ? a1 : an;

@@ -312,12 +312,22 @@ __device__ __forceinline__ void sincos_fast_f64(double x, double *s, double *c) 
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
   const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2), S1);
   const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
-  const double ks = __builtin_fma(r * z, ps, r);
-  const double kc = __builtin_fma(z, __builtin_fma(z, pc, -0.5), 1.0);
-  const int q = (int)k;
-  const double sa = (q & 1) ? kc : ks, ca = (q & 1) ? ks : kc;
-  *s = (q & 2) ? -sa : sa;
-  *c = ((q + 1) & 2) ? -ca : ca;
+  // Quadrant q = k mod 4:  q  sin   cos     The sin kernel ks is odd in r, so its sign is applied to r BEFORE the
+  //                        0  +ks   +kc     polynomial (one xor); kc's sign after it; then one swap.  Signs as
+  //                        1  +kc   -ks     sign-bit masks straight from the bits of q: sign(kc) = bit 1 of q,
+  //                        2  -ks   -kc     sign(ks) = bit 1 ^ bit 0.  11 integer/select instructions instead of the
+  //                        3  -kc   +ks     ~15 that the obvious selects compile to, four times per step.
+  const uint32_t q = (uint32_t)(int)k;
+  const uint32_t odd = q << 31;                          // bit 0 of q in the sign position
+  const uint32_t m_kc = (q >> 1) << 31;                  // bit 1 of q
+  const uint32_t m_ks = m_kc ^ odd;
+  const double rs = __hiloint2double((int)(__double2hiint(r) ^ m_ks), __double2loint(r));
+  const double ks = __builtin_fma(rs * z, ps, rs);
+  const double kc0 = __builtin_fma(z, __builtin_fma(z, pc, -0.5), 1.0);
+  const double kc = __hiloint2double((int)(__double2hiint(kc0) ^ m_kc), __double2loint(kc0));
+  const bool swap = (int)odd < 0;
+  *s = swap ? kc : ks;
+  *c = swap ? ks : kc;
 }
 
 template <typename R> struct Ang;
