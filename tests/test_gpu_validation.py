@@ -211,3 +211,30 @@ def test_failure_counters(ps, oracle):
             assert red[ps.NRED - 2] == s.nan_rejects and red[ps.NRED - 1] == s.chains_collapsed
             e.reset_averages()
             assert e.summary().nan_rejects == 0
+
+
+def test_a_timed_out_launch_poisons_the_handle(ps, monkeypatch):
+    """a segment job that gives up waiting for its predecessor used to be visible in pstat_sync only, and the
+    next launch wiped the flag.  Forced here (a 1-spin bound with every (block, segment) job co-resident: the second
+    segments start while the first are still running and give up at once; the kernel then stops taking jobs and ends
+    normally).  Every accessor that would hand out results, and every further advance, must fail with PSTAT_ERR_HIP --
+    the averages would be over steps that never ran -- and the failure must survive later calls.  Other handles are
+    unaffected."""
+    monkeypatch.setenv("PSTAT_SEGMENTS", "7")
+    monkeypatch.setenv("PSTAT_MAX_SPINS", "1")
+    e = ps.Ensemble(ps.default_params(num_chains=4096, precision=ps.F32, n=40, E0=1.0, Fz=0.5, seed=6))
+    try:
+        e.advance(70000)
+        calls = [e.sync, e.summary, e.rolling, lambda: e.microstate(0), lambda: e.chain_state(0), e.reduce_host,
+                 e.checkpoint, lambda: e.chain_means(), lambda: e.advance(10), e.summary]
+        for f in calls:
+            with pytest.raises(ps.PstatError) as ei:
+                f()
+            assert ei.value.code == -3 and "did not complete" in str(ei.value), str(ei.value)
+    finally:
+        e.close()
+    monkeypatch.delenv("PSTAT_SEGMENTS")
+    monkeypatch.delenv("PSTAT_MAX_SPINS")
+    with ps.Ensemble(ps.default_params(num_chains=4096, precision=ps.F32, n=40, E0=1.0, Fz=0.5, seed=6)) as ok:
+        ok.advance(7000)
+        assert ok.summary().steps_per_chain == 7000
