@@ -353,6 +353,31 @@ def test_reinit_force_and_metropolis(ps, oracle):
                 np.testing.assert_allclose(g["sums"], o.sums, rtol=1e-9, atol=1e-7)
 
 
+def test_reinit_under_umbrella_sampling_carries_the_weight_in_the_stale_cache(ps, oracle):
+    """the acceptor's cached log-density includes the umbrella weight w = sum(u) * wscale
+    (inc/acceptance.jl:13-16, inc/average.jl:104-124); after an adopted re-initialisation the comparisons are offset by
+    lp_old - lp_new INCLUDING w.  With E0 = 3 the weight differs by O(10) between two random configurations, so a re-init
+    kernel that left it out (round 1) takes different decisions from the oracle within a few steps.  Sweep kernels, LDS
+    (n = 24) and state-in-memory (n = 60) variants, non-interacting and Ising, forced and Metropolis re-init."""
+    for force, n, et in ((1, 24, 0), (0, 24, 0), (1, 60, 0), (1, 24, 2), (1, 60, 2)):
+        nsteps, inits = 900, 4
+        kw = dict(n=n, E0=3.0, K1=1.0 if et == 0 else 0.2, K2=0.1 if et == 0 else 0.02, Fz=0.2, umbrella=1, energy_type=et,
+                  seed=77, steps_per_adjust=300)
+        op, pp = both(nsteps, num_chains=16, precision=ps.F64, num_inits=inits, force_init=force, **kw)
+        with ps.Ensemble(pp) as e:
+            for k in range(inits):
+                e.advance(nsteps)
+                if k + 1 < inits:
+                    e.reinit(bool(force))
+            dw = []
+            for c in range(16):
+                o = oracle.run(op, chain_id=c, mode="fast", trace=True)
+                g = e.chain_state(c)
+                assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (force, n, et, c)
+                assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total, (force, n, et, c)
+                np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-8, atol=1e-8)
+
+
 def test_errors_are_loud(ps):
     with pytest.raises(ps.PstatError):
         ps.Ensemble(ps.default_params(n=0))
