@@ -35,22 +35,7 @@ template <typename R> struct V3 { R x, y, z; };
 template <typename R> __device__ __forceinline__ R dot3(const V3<R> &a, const V3<R> &b) {
   return a.x * b.x + a.y * b.y + a.z * b.z;
 }
-// acos on [-1, 1] as sqrt(1 - |x|) * P7(|x|) (Abramowitz & Stegun 4.4.46, |error| <= 2e-8 -- below the
-// f32 spacing of the result), mirrored for x < 0: a dozen full-rate ops and one v_sqrt
-__device__ __forceinline__ float acos_r(float x) {
-  const float a = fabsf(x);
-  float p = -0.0012624911f;
-  p = __builtin_fmaf(p, a, 0.0066700901f);
-  p = __builtin_fmaf(p, a, -0.0170881256f);
-  p = __builtin_fmaf(p, a, 0.0308918810f);
-  p = __builtin_fmaf(p, a, -0.0501743046f);
-  p = __builtin_fmaf(p, a, 0.0889789874f);
-  p = __builtin_fmaf(p, a, -0.2145988016f);
-  p = __builtin_fmaf(p, a, 1.5707963050f);
-  const float r = __builtin_amdgcn_sqrtf(fmaxf(1.0f - a, 0.0f)) * p;
-  return x < 0.0f ? 3.14159265358979f - r : r;
-}
-__device__ __forceinline__ double acos_r(double x) { return acos(x); }
+// (acos_r: pstat_math.h)
 
 // psi_j, inc/eap_chain.jl:45-47
 template <typename R> __device__ __forceinline__ R bond_angle(const V3<R> &a, const V3<R> &b) {

@@ -113,8 +113,8 @@ __global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? PSTAT_IOCC_F64M1 : (
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       R ct, sp, cp;
-      AG::sc(th[j], &st[j], &ct);
-      AG::sc(ph[j], &sp, &cp);
+      AG::sc_theta(th[j], &st[j], &ct);
+      AG::sc_phi(ph[j], &sp, &cp);
       nx[j] = real[j] ? cp * st[j] : (R)0; ny[j] = real[j] ? sp * st[j] : (R)0; nz[j] = real[j] ? ct : (R)0;
       dipole<R, CT>(a_or_mu, k2e, nx[j], ny[j], nz[j], mx[j], my[j], mz[j]);
       if (!real[j]) { mx[j] = 0; my[j] = 0; mz[j] = 0; }
@@ -234,8 +234,8 @@ __global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? PSTAT_IOCC_F64M1 : (
       const R ph1 = AG::wrap(ph0 + dphi);
       const R th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
       R st1, ct1, sp1, cp1;
-      AG::sc(th1, &st1, &ct1);
-      AG::sc(ph1, &sp1, &cp1);
+      AG::sc_theta(th1, &st1, &ct1);
+      AG::sc_phi(ph1, &sp1, &cp1);
       const R n1x = cp1 * st1, n1y = sp1 * st1, n1z = ct1;
       R m1x, m1y, m1z;
       dipole<R, CT>(a_or_mu, k2e, n1x, n1y, n1z, m1x, m1y, m1z);

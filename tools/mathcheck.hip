@@ -10,12 +10,23 @@
 
 #include "../polymer_stats_amd/csrc/pstat_math.h"
 
-__global__ void run(const double *x, double *s, double *c, double *ex, double *lg, double *sf, double *cf, int n) {
+// argument of the acos check: 2^24 points of [-1, 1], the same double on device and host; the first few are special
+__host__ __device__ inline double acos_arg(int i) {
+  if (i == 0) return 1.0;
+  if (i == 1) return -1.0;
+  if (i == 2) return 0.5;
+  if (i == 3) return -0.5;
+  if (i == 4) return 0.0;
+  return (double)(((unsigned)i * 2654435761u) >> 8) / 8388608.0 - 1.0;
+}
+
+__global__ void run(const double *x, double *s, double *c, double *ex, double *lg, double *sf, double *cf, double *ac, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   pstat::sincos_f64(x[i], &s[i], &c[i]);
   if (x[i] >= 0.0 && x[i] <= M_PI) pstat::sincos_fast_f64<true>(x[i], &sf[i], &cf[i]);   // the sweep's hot-loop form
   else pstat::sincos_fast_f64<false>(x[i], &sf[i], &cf[i]);
+  ac[i] = pstat::acos_r(acos_arg(i));               // the clustering main's bond angles (f64 form)
   ex[i] = pstat::exp_f64(-fabs(x[i]) * 0.007);     // the acceptance test only ever needs exp of negatives
   lg[i] = pstat::log_f64(fabs(x[i]));
 }
@@ -37,18 +48,19 @@ int main() {
   const double special[] = {0.0, M_PI, M_PI / 2, M_PI / 4, 3 * M_PI / 4, -M_PI, 2 * M_PI, 1e-300, 9e4, -7e4, std::nextafter(M_PI, 0.0), 1.0};
   const int nsp = (int)(sizeof special / sizeof *special);
   for (int i = 0; i < nsp; ++i) x[i] = special[i];
-  double *d[7];
+  double *d[8];
   for (auto &p : d) if (hipMalloc(&p, n * 8) != hipSuccess) return 2;
   if (hipMemcpy(d[0], x.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) return 2;
-  hipLaunchKernelGGL(run, dim3(n / 256), dim3(256), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], d[6], n);
-  std::vector<double> s(n), c(n), ex(n), lg(n), sf(n), cf(n);
+  hipLaunchKernelGGL(run, dim3(n / 256), dim3(256), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], n);
+  std::vector<double> s(n), c(n), ex(n), lg(n), sf(n), cf(n), ac(n);
+  if (hipMemcpy(ac.data(), d[7], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(sf.data(), d[5], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(cf.data(), d[6], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(s.data(), d[1], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(c.data(), d[2], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(ex.data(), d[3], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(lg.data(), d[4], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
-  double ms = 0, mc = 0, me = 0, ml = 0, msf = 0, mcf = 0;
+  double ms = 0, mc = 0, me = 0, ml = 0, msf = 0, mcf = 0, mac = 0;
   int bad = 0;
   for (int i = 0; i < n; ++i) {
     const double es = ulps(s[i], sinl((long double)x[i])), ec = ulps(c[i], cosl((long double)x[i]));
@@ -61,6 +73,12 @@ int main() {
     const double efc = fmin(ulps(cf[i], wc), (double)(fabsl((long double)cf[i] - wc) / 1.1102230246251565e-16L));
     msf = fmax(msf, efs); mcf = fmax(mcf, efc);
     if (efs > 1.5 || efc > 1.5) ++bad;
+    {
+      const long double wa = acosl((long double)acos_arg(i));
+      const double ea = wa == 0.0L ? (ac[i] == 0.0 ? 0.0 : 1e9) : ulps(ac[i], wa);
+      mac = fmax(mac, ea);
+      if (ea > 1.5) ++bad;
+    }
     const double a = fabs(x[i]);
     const double arg = -a * 0.007;                  // the same double the device saw
     const double ee = ulps(ex[i], expl((long double)arg));
@@ -69,6 +87,7 @@ int main() {
     if (ee > 2.0) ++bad;
   }
   printf("over %d arguments: max error sin %.3f ulp, cos %.3f ulp, exp %.3f ulp, log %.3f ulp; %d out of bounds\n", n, ms, mc, me, ml, bad);
+  printf("acos_r (f64): max error %.3f ulp; acos(1) = %g, acos(-1) = %.17g\n", mac, ac[0], ac[1]);
   printf("fast hot-loop form: max error sin %.3f, cos %.3f (ulp of the result, or units of 2^-53 next to a zero); sin(fl(pi)) = %.17g, "
          "cos(fl(pi/2)) = %.17g, sin(0) = %g\n", msf, mcf, sf[1], cf[2], sf[0]);
   printf("sin(fl(pi)) = %.17g (glibc %.17g)  cos(fl(pi/2)) = %.17g (glibc %.17g)  sin(0) = %g  log(0) = %g  log(1) = %g\n", s[1],
