@@ -2,12 +2,15 @@
 //
 // Mapping: ONE INDEPENDENT MARKOV CHAIN PER WAVEFRONT LANE.  A workgroup is
 // a single wave64; lane l of workgroup g owns chain g*lanes + l for the whole launch.
-//   * the chain's orientation angles (theta_i, phi_i), i < n, live in LDS as [monomer][lane] R2
-//     pairs: lane l only ever touches column l, so no barrier or cross-lane traffic is needed and a
-//     per-lane random monomer index is bank-conflict-free (ds_read_b64: bank = (2*lane + k) mod 64);
-//   * the generator (xoshiro128++), step sizes, adaptation counters, end-to-end vector r, dipole p,
+//   * the chain's orientation angles (theta_i, phi_i), i < n, are "cells" [monomer][lane]: lane l only ever touches
+//     column l, so no barrier or cross-lane traffic is needed.  f32 / q16 and short f64 chains keep every cell in
+//     LDS (a per-lane random monomer index is bank-conflict-free); the f64 sweep of longer chains (n > 40) keeps the
+//     first 39 rows in LDS and the rest in a global working buffer that it reads two steps ahead through L2 /
+//     Infinity Cache (run_segment, ST = 2);
+//   * the generator (MWC64X or xoshiro128++), step sizes, adaptation counters, end-to-end vector r, dipole p,
 //     energy U and the running sums stay in registers;
-//   * HBM is touched only to fill LDS/registers at launch start and to spill them at the end.
+//   * HBM holds the checkpoint layout (struct-of-arrays over the chain index); it is touched only to fill the
+//     cells/registers at launch start and to spill them at the end.
 // There is no dense contraction anywhere on this path, hence no MFMA.
 //
 // Reference semantics implemented (file:line relative to the reference tree):

@@ -2,7 +2,7 @@
 """BASELINE configs[4]: (E0, kT) phase-diagram scan at n = 200 (grid of run/K1_E0-kT-phase.jl:21-24:
 E0 in 0:0.2:5, kT in 10^(-2:0.2:2), K1 = 1, K2 = 0, b = 1, F = 0), all 546 grid points in ONE
 batched launch per GPU.  Chains of every grid point are sharded over the ranks by global chain id;
-the only exchange is one all-reduce(SUM) of the [points x 39] reduction tensor (RCCL when launched
+the only exchange is one all-reduce(SUM) of the [points x 41] reduction tensor (RCCL when launched
 with torch.distributed.run, nothing at all for one GPU).
 
     python tools/phase_scan.py --chains 128 --steps 50000 --burn-in 20000 --energy Ising --out scan.csv
@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50000)
     ap.add_argument("--burn-in", type=int, default=20000)
     ap.add_argument("--energy", choices=["noninteracting", "Ising"], default="Ising")
-    ap.add_argument("--precision", choices=["f32", "f64", "q16"], default="f32")
+    ap.add_argument("--precision", choices=["f32", "f64", "q16"], default="f64", help="f64 = the reference's arithmetic (default); f32 / q16 = fast paths")
     ap.add_argument("--main", choices=["fixed-force", "clustering"], default="fixed-force",
                     help="which main's step: mcmc_eap_chain.jl or mcmc_clustering_eap_chain.jl (cluster flips)")
     ap.add_argument("--burn-schedule", default="1", help="kT multipliers of the burn-in ladder, comma-separated")
