@@ -157,11 +157,11 @@ function wide_merge(handles, num_chains_of, T)
     check(ccall((:pstat_chain_means, LIBPSTAT), Cint, (Ptr{Cvoid}, Int32, Ptr{Cdouble}), h, -1, buf))
     push!(cols, buf)
   end
-  all = vcat(cols...)
-  C = size(all, 1)
-  mean = [sum(T.(all[:, q])) / C for q = 1:NQ]
-  se = [C > 1 ? sqrt(sum((T.(all[:, q]) .- mean[q]) .^ 2) / (C - 1) / C) : zero(T) for q = 1:NQ]
-  return mean, se
+  m = vcat(cols...)
+  C = size(m, 1)
+  avg = [sum(T.(m[:, q])) / C for q = 1:NQ]
+  se = [C > 1 ? sqrt(sum((T.(m[:, q]) .- avg[q]) .^ 2) / (C - 1) / C) : zero(T) for q = 1:NQ]
+  return avg, se
 end
 
 function report_failures(sm)
@@ -267,7 +267,7 @@ function mcmc(nsteps::Int, pargs)
   if pargs["numeric-type"] != "float64"
     T = wide_type(pargs["numeric-type"])
     @warn "--numeric-type $(pargs["numeric-type"]): per-chain sums are Float64 on the device; the merge over chains is carried out in $T";
-    (wmean, _) = wide_merge(handles, counts, T)
+    (wmean, _) = Base.invokelatest(wide_merge, handles, counts, T)   # (T's methods may come from a package loaded just now)
     a = wmean[1:NOBS]; ar = wmean[NOBS + 1]
   end
   for h in handles
