@@ -10,11 +10,11 @@ contact, |U| > 1e3 n kT).  There a position rounding of 1e-15 b -- the kernel su
 oracle sequentially -- moves the contact's term by ~1e-5 kT, enough to flip a decision every ~1e5 steps; the reference
 itself would not reproduce such a chain across machines.  (Measured: 3 of ~400 interacting trials.)
 
-    python tools/fuzz_f64.py [trials=400] [seed=1]"""
+    python tests/fuzz_f64.py [trials=400] [seed=1]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (this file lives in tests/: it runs the oracle, which only test code may)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
