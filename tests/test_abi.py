@@ -107,6 +107,14 @@ def test_product_never_touches_the_oracle():
                 assert "eap_oracle" not in code, (f, code)
     out = subprocess.check_output(["ldd", os.path.join(pkg, "libpstat.so")]).decode()
     assert "oracle" not in out
+    # tools/ measure and profile the product: they may not use the checker either.  bench.py may, in its cpu_baseline leg only.
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            text = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
+            assert "from oracle" not in text and "import oracle" not in text and "liboracle" not in text, f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle") == 1 and bench.index("from oracle") > bench.index("def cpu_baseline")
+    assert bench.index("from oracle") < bench.index("def parity_vs_cpu")
 
 
 def test_julia_hosts_mirror_the_structs(ps):
