@@ -151,6 +151,25 @@ def test_config4_as_stated_f32_against_f64(ps):
     assert a.chains_collapsed > 0.2 * 16384 and b.chains_collapsed > 0.2 * 16384
 
 
+def test_config4_as_stated_f64_against_the_oracle_in_distribution(ps, oracle):
+    """BASELINE configs[3] as stated, f64 kernel against the oracle's literal O(n^2) mode as two independent samples.
+    On collapsed chains a 1e-15 rounding of a position can flip a decision (the trajectory fuzz), so bit
+    parity is not the right question there; equality in distribution is: <r>, <r_j^2>, <p>, AR within 5 sigma."""
+    nsteps = 20000
+    op, pp = both(nsteps, num_chains=16384, precision=ps.F64, n=64, E0=1.0, K1=1.0, K2=0.0, Fz=0.5,
+                  energy_type=ps.INTERACTING, seed=61)
+    with ps.Ensemble(pp) as e:
+        e.advance(nsteps)
+        s = e.summary()
+    osums, onorm, onacc = oracle.run_many(op, 9_000_000, 192, nthreads=16, mode="faithful")
+    o_avg, o_se = pooled(osums, onorm)
+    for k in (0, 1, 2, 3, 4, 5, 7, 8, 9):
+        z = (s.avg[k] - o_avg[k]) / np.hypot(s.stderr[k], o_se[k])
+        assert abs(z) < 5.0, (ps.OBS_NAMES[k], s.avg[k], o_avg[k], z)
+    o_ar = onacc / nsteps
+    assert abs(s.acceptance_ratio - o_ar.mean()) < 5 * np.hypot(s.ar_stderr, o_ar.std(ddof=1) / np.sqrt(len(o_ar)))
+
+
 def test_f64_state_in_memory_matches_state_in_lds(ps, monkeypatch):
     """The f64 non-interacting sweep keeps its (theta, phi) cells in global memory (L2 / Infinity Cache) once LDS would
     seat fewer than four full waves per CU (n > 40), else in LDS.  Same kernel template, two homes for the state: forced
