@@ -152,3 +152,25 @@ def test_julia_hosts_mirror_the_structs(ps):
         # every ccall names a symbol the library exports
         for sym in set(re.findall(r"ccall\(\(:(\w+), LIBPSTAT\)", src)):
             assert sym in ps._lib.SYMBOLS, (name, sym)
+
+
+def build_c_client(tmp_path):
+    exe = tmp_path / "abi_smoke"
+    pkg = os.path.join(ROOT, "polymer_stats_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", str(exe),
+                           "-L", pkg, "-lpstat", "-lm", "-Wl,-rpath," + pkg])
+    return exe
+
+
+def test_plain_c_client_links_and_fails_loudly_without_a_gpu(ps, tmp_path):
+    """The boundary is a C ABI: a C11 translation unit that includes only include/pstat.h links against libpstat.so and
+    runs.  Without a GPU it gets PSTAT_ERR_NO_DEVICE and a message (exit code 2 of the client); with one it runs the
+    ensemble (tests/test_gpu_host.py checks the numbers)."""
+    exe = build_c_client(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    if ps._lib.load().pstat_device_count() > 0:
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 2, r.stdout + r.stderr
+        assert "no HIP device" in r.stdout and "no CPU path" in r.stdout

@@ -163,3 +163,14 @@ def test_numeric_type_wide_merge_matches_float64_and_warns(tmp_path, capsys):
     for la, lb in zip(a.splitlines(), b.splitlines()):
         va, vb = (np.array(eval(l.split("=")[1]), dtype=float) for l in (la, lb))
         np.testing.assert_allclose(vb, va, rtol=1e-12, atol=1e-13)
+
+
+def test_plain_c_client_runs_the_ensemble(tmp_path):
+    """tests/c/abi_smoke.c: a C program on include/pstat.h alone -- create, burn-in, reset, advance, summary, destroy --
+    lands on the freely-jointed-chain closed form (BASELINE configs[0])."""
+    import subprocess
+    from test_abi import build_c_client
+    exe = build_c_client(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "chains = 2048" in r.stdout and "steps = 30000" in r.stdout and "nan_rejects = 0" in r.stdout
