@@ -327,6 +327,11 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
     int best = lanes;
     double best_cost = 1e300;
     const char *le = getenv("PSTAT_LANES");
+    bool lds_starved = false;     // full waves: fewer than one per SIMD fit a CU's LDS
+    {
+      int lds0 = 0, bpc0 = 0;
+      lds_starved = kernel_info(h->cfg, h->args, &lds0, &bpc0, nullptr) == hipSuccess && bpc0 < 4;
+    }
     for (int cand = lanes; cand >= 16; --cand) {
       if (le && atoi(le) >= 1 && atoi(le) <= lanes && cand != atoi(le)) continue;
       SweepArgs probe = h->args;
@@ -338,6 +343,16 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
       double cost = wgs / slots;
       if (cost < 1.0) cost = 1.0;
       cost *= 1.0 + 1e-4 * (64 - cand);   // ties: prefer fuller waves
+      if (h->cfg.move_set == PSTAT_MOVES_CLUSTER && lds_starved) {
+        // (only when LDS seats fewer than four FULL waves per CU.)  The cluster step runs a wave for as long as its
+        // LONGEST cluster, so a wave of fewer lanes finishes its steps sooner (~ log of the lane count), and more,
+        // emptier waves also put the idle SIMDs to work.  Measured, n = 100, f64 (LDS seats 102 chains per CU): 4 x 25 lanes
+        // 4.08e9 proposals/s against 2 x 51 lanes 3.61e9 (non-interacting; Ising 5.70e9 / 5.57e9).  Sharing a SIMD
+        // between waves costs more than it gains here (f32: 4 x 51 lanes 1.77e10, 8 x 25 lanes 1.52e10).
+        const double waves_per_simd = bpc / 4.0;
+        cost *= 1.0 + 0.1 * std::log2(cand / 16.0);
+        if (waves_per_simd > 1.0) cost *= 1.0 + 0.25 * (waves_per_simd - 1.0);
+      }
       if (cost < best_cost) { best_cost = cost; best = cand; }
     }
     lanes = best;
