@@ -332,7 +332,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
       int lds0 = 0, bpc0 = 0;
       lds_starved = kernel_info(h->cfg, h->args, &lds0, &bpc0, nullptr) == hipSuccess && bpc0 < 4;
     }
-    for (int cand = lanes; cand >= 16; --cand) {
+    for (int cand = lanes; cand >= 8; --cand) {
       if (le && atoi(le) >= 1 && atoi(le) <= lanes && cand != atoi(le)) continue;
       SweepArgs probe = h->args;
       probe.lanes = cand;
