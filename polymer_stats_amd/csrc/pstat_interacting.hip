@@ -50,10 +50,14 @@ template <typename R, typename G, int CT, int M>
 #ifndef PSTAT_IOCC_F64M2
 #define PSTAT_IOCC_F64M2 2
 #endif
+#ifndef PSTAT_IOCC_F64M4
+#define PSTAT_IOCC_F64M4 1   // (measured round 2 with the rsq-Newton term: F64M2 / F64M4 = 2/1 1.34e8 | 3.38e7 at n = 100 | 200;
+                             //  2/2 1.34e8 | 3.23e7; 3/1 1.20e8 | 3.38e7: the round-1 choice stands)
+#endif
 #ifndef PSTAT_IOCC_F64M1
 #define PSTAT_IOCC_F64M1 3   // (measured round 2, n = 64: 2 waves 3.47e8, 3 waves see DESIGN, 4 waves 2.68e8 -- spills)
 #endif
-__global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? PSTAT_IOCC_F64M1 : (M == 2 ? PSTAT_IOCC_F64M2 : 1))
+__global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? PSTAT_IOCC_F64M1 : (M == 2 ? PSTAT_IOCC_F64M2 : PSTAT_IOCC_F64M4))
                                                 : (M == 1 ? PSTAT_IOCC_M1 : (M == 2 ? PSTAT_IOCC_M2 : PSTAT_IOCC_M4))) void interacting_kernel(SweepArgs A, DevState S,
                                                          const CaseConst *__restrict__ cases,
                                                          int do_flips, int use_lag, int umb,
