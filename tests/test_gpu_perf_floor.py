@@ -1,0 +1,58 @@
+"""Throughput floors on the GPU box: not a benchmark (bench.py is), a tripwire.  Each floor is about half of what the
+configuration measured on MI355X in round 2, so box-to-box differences cannot trip it, while the
+kind of accident that does happen -- a launch-shape chooser picking a bad lane count, a kernel falling back to a slow
+variant, state no longer where it should be -- costs more than that."""
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ps():
+    import polymer_stats_amd as ps
+    assert ps._lib.load().pstat_device_count() >= 1, "no HIP device visible"
+    return ps
+
+
+def _rate(ps, steps, **kw):
+    with ps.Ensemble(ps.default_params(**kw)) as e:
+        e.advance(max(500, steps // 10))
+        e.sync()
+        t0 = time.perf_counter()
+        e.advance(steps)
+        e.sync()
+        dt = time.perf_counter() - t0
+        return kw["num_chains"] * steps / dt, e.launch_info()
+
+
+CASES = [
+    # name, floor (updates or proposals per second), steps, expected kernel substring, parameters
+    ("f64 sweep n=100 (bench workload)", 4.5e10, 40000, "state in L2",
+     dict(n=100, E0=1.0, K1=1.0, Fz=1.0, num_chains=65536, precision=1, seed=1)),
+    ("f32 sweep n=100 (fast path)", 1.6e11, 100000, "sweep_kernel<float>",
+     dict(n=100, E0=1.0, K1=1.0, Fz=1.0, num_chains=65536, precision=0, seed=1)),
+    ("q16 sweep n=100", 1.6e11, 100000, "q16",
+     dict(n=100, E0=1.0, K1=1.0, Fz=1.0, num_chains=65536, precision=2, seed=1)),
+    ("f64 Ising sweep n=200", 1.2e10, 20000, "state in L2",
+     dict(n=200, E0=1.0, K1=1.0, kT=1.0, energy_type=2, num_chains=65536, precision=1, seed=1)),
+    ("f64 all-pairs n=64", 1.6e8, 2000, "interacting_kernel<double>",
+     dict(n=64, E0=1.0, K1=1.0, Fz=0.5, energy_type=1, num_chains=16384, precision=1, seed=1)),
+    ("f32 all-pairs n=64", 4.0e8, 4000, "interacting_kernel<float>",
+     dict(n=64, E0=1.0, K1=1.0, Fz=0.5, energy_type=1, num_chains=16384, precision=0, seed=1)),
+    ("f32 clustering main n=100", 8.0e9, 5000, "cluster_kernel<float>",
+     dict(n=100, E0=1.0, K1=0.0, K2=1.0, num_chains=65536, precision=0, seed=1, move_set=1, cluster_prob=0.5, adj_ub=0.40)),
+    ("q16 clustering main n=100", 9.0e9, 5000, "cluster_kernel",
+     dict(n=100, E0=1.0, K1=0.0, K2=1.0, num_chains=65536, precision=2, seed=1, move_set=1, cluster_prob=0.5, adj_ub=0.40)),
+    ("f64 clustering main n=100", 1.8e9, 3000, "cluster_kernel<double>",
+     dict(n=100, E0=1.0, K1=0.0, K2=1.0, num_chains=65536, precision=1, seed=1, move_set=1, cluster_prob=0.5, adj_ub=0.40)),
+]
+
+
+@pytest.mark.parametrize("name,floor,steps,kernel,kw", CASES, ids=[c[0] for c in CASES])
+def test_throughput_floor(ps, name, floor, steps, kernel, kw):
+    rate, info = _rate(ps, steps, **kw)
+    assert kernel in info.kernel.decode(), info.kernel.decode()
+    assert rate > floor, f"{name}: {rate:.3e} per second, floor {floor:.1e} ({info.kernel.decode()}, " \
+                         f"{info.lanes_per_block} lanes x {info.blocks_per_cu} workgroups per CU)"
