@@ -360,14 +360,9 @@ WaveFn pick_m(const LaunchCfg &cfg, int64_t n) {
   const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
   if (n <= 64) return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 1> : cluster_wave_kernel<R, G, PSTAT_POLAR, 1>;
   if (n <= 128) return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 2> : cluster_wave_kernel<R, G, PSTAT_POLAR, 2>;
-  if constexpr (sizeof(R) == 8) {
-    return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 4> : cluster_wave_kernel<R, G, PSTAT_POLAR, 4>;
-  } else {
-    if (n <= 256) return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 4> : cluster_wave_kernel<R, G, PSTAT_POLAR, 4>;
-    // 8 monomers per lane (n <= 512; the reference's only cutoff-energy sweep, run/phases-big_2023-05-18.jl, uses
-    // n = 400): f32 only -- in f64 two configurations of 8 monomers per lane do not fit the register file
-    return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 8> : cluster_wave_kernel<R, G, PSTAT_POLAR, 8>;
-  }
+  if (n <= 256) return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 4> : cluster_wave_kernel<R, G, PSTAT_POLAR, 4>;
+  // 8 monomers per lane (n <= 512; the reference's only cutoff-energy sweep, run/phases-big_2023-05-18.jl, uses n = 400)
+  return diel ? cluster_wave_kernel<R, G, PSTAT_DIELECTRIC, 8> : cluster_wave_kernel<R, G, PSTAT_POLAR, 8>;
 }
 
 }  // namespace

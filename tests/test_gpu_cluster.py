@@ -162,7 +162,7 @@ def test_f64_all_pairs_burn_in_ladder(ps, oracle):
 
 
 def test_f32_cutoff_long_chain_statistics(ps, oracle):
-    """n = 300: 8 monomers per lane (f32 only), the regime of the reference's only cutoff-energy sweep
+    """n = 300: 8 monomers per lane, the regime of the reference's only cutoff-energy sweep
     (run/phases-big_2023-05-18.jl: n = 400, --energy-type cutoff).  Short run against the literal oracle."""
     kw = dict(n=300, E0=1.0, K1=0.3, K2=0.03, Fz=0.3, kT=1.0, seed=54, cluster_prob=0.5, energy_type=3, cutoff_radius=7.5)
     nsteps = 600
@@ -179,9 +179,18 @@ def test_f32_cutoff_long_chain_statistics(ps, oracle):
     assert np.all(np.abs(z) < 4.5), (z, gm, om)
     oar = nacc / nsteps
     assert abs(s.acceptance_ratio - oar.mean()) < 4.5 * np.hypot(s.ar_stderr, oar.std(ddof=1) / np.sqrt(len(oar))) + 1e-3
-    with pytest.raises(ps.PstatError) as ei:       # f64 stops at 4 monomers per lane
-        ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, n=300, energy_type=3, precision=ps.F64))
+    with pytest.raises(ps.PstatError) as ei:       # 8 monomers per lane is the limit, in either precision
+        ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, n=513, energy_type=3, precision=ps.F64))
     assert ei.value.code == -4
+
+
+@pytest.mark.parametrize("et", [3, 1], ids=["cutoff", "interacting"])
+def test_f64_long_chain_all_pairs_bit_parity(ps, oracle, et):
+    """f64 (the hosts' default) at 8 monomers per lane: n = 300 and the reference's n = 400 (run/phases-big_2023-05-18.jl),
+    trajectories bit for bit against the oracle's literal clustering main (weak coupling: no collapse in 150 steps)."""
+    for n in (300, 400):
+        _bit_parity(ps, oracle, 150, 3, n=n, E0=1.0, K1=0.3, K2=0.03, Fz=0.3, kT=1.0, seed=56, cluster_prob=0.5,
+                    energy_type=et, cutoff_radius=7.5, steps_per_adjust=50)
 
 
 def test_f32_all_pairs_cluster_statistics(ps, oracle):
