@@ -289,7 +289,7 @@ def test_cluster_full_size_properties(ps):
 
 
 def test_cluster_errors(ps):
-    for bad in (dict(energy_type=1, n=600), dict(energy_type=1, n=300, precision=ps.F64), dict(energy_type=1, precision=ps.Q16),
+    for bad in (dict(energy_type=1, n=600), dict(energy_type=1, n=600, precision=ps.F32), dict(energy_type=1, precision=ps.Q16),
                 dict(energy_type=3, precision=ps.Q16)):
         with pytest.raises(ps.PstatError) as ei:
             ps.Ensemble(ps.default_params(move_set=ps.MOVES_CLUSTER, **{"n": 16, **bad}))
