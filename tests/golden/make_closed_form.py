@@ -8,6 +8,13 @@ inc/energy.jl:7-9, inc/eap_chain.jl:53, inc/dipole_response.jl:7-29)
     rho(theta, phi) ~ sin(theta) * exp(-[u(theta) - b (Fx sin(theta) cos(phi) + Fz cos(theta))] / kT)
     u = -1/2 E0 mu_z,  mu = (K1-K2) E0 cos(theta) n + K2 E0 z   (dielectric)   or   mu * n  (polar)
 
+For the dielectric chain this is the density the reference's own mean-field solver integrates,
+rho = c exp(-omega0 cos^2(theta) + lambda cos(theta) + alpha cos(phi) sin(theta)) with the measure sin(theta)
+(inc/solvers.jl:88-98, mean_field.jl:136): its force-ensemble reading has lambda = Fz b / kT, alpha = Fx b / kT,
+omega0 = -(K1-K2) E0^2 / (2 kT) (the K2 term of u is a constant).  The reference cross-checks its MCMC against that
+solver for non-interacting chains (run/noninteracting-compare-with-clustering_2021-09-24.jl); these fixtures are the
+same check with the integrals done here.
+
 and then   <r> = n b <n>,  <r_j^2> = n b^2 Var(n_j) + <r_j>^2,  <p> = n <mu>,
            <p_j^2> = n Var(mu_j) + <p_j>^2,  <U> = n <w>,  <U^2> = n Var(w) + <U>^2,
 with w = u - b F.n the one-monomer energy.  Cross terms vanish by independence.
