@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/pstat.h"
+#include "pstat_cluster_common.h"
 #include "pstat_device.h"
 
 using namespace pstat;
@@ -289,7 +290,8 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   A.adaptive = (h->base.adj_scale != 1.0 && h->base.steps_per_adjust > 0) ? 1 : 0;  // mcmc_eap_chain.jl:302
   A.ncases = ncases; A.seg_len = 0; A.nseg = 1; A.max_spins = 1 << 22;
   A.lds_rows = 0; A.pad_ = 0;
-  if (h->cfg.state_global) {   // a quarter of a CU's LDS per wave: four resident waves, 64 lanes x 16 B per row
+  const bool cluster_gm = h->cfg.state_global && h->cfg.move_set == PSTAT_MOVES_CLUSTER;   // pstat_cluster_gm.hip
+  if (h->cfg.state_global && !cluster_gm) {   // a quarter of a CU's LDS per wave: four resident waves, 64 lanes x 16 B per row
     int rows = 160 * 1024 / 4 / (64 * 16) - 1;   // one row of the quarter is the trash row of run_segment
     const char *e = getenv("PSTAT_F64_LDS_ROWS");
     if (e && atoi(e) >= 0 && atoi(e) <= rows) rows = atoi(e);
@@ -357,6 +359,35 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
     A.lanes = lanes;
     A.blocks_per_case = (h->base.num_chains + lanes - 1) / lanes;
   }
+  if (cluster_gm) {
+    // Chains in device memory: nothing limits a wave to fewer than 64 lanes, but an ensemble of fewer waves than the
+    // chip has SIMDs (a phase scan: 546 grid points x 64 chains) runs faster as more, emptier waves -- they fill the
+    // idle SIMDs, and a wave's step lasts as long as its LONGEST cluster, which grows like the logarithm of its lanes.
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, h->device));
+    int lds0 = 0, bpc = 0;
+    CREATE_HIP(kernel_info(h->cfg, h->args, &lds0, &bpc, nullptr));
+    const double slots = (double)(bpc > 0 ? bpc : 1) * prop.multiProcessorCount;
+    const char *le = getenv("PSTAT_LANES");
+    int best = 64;
+    double best_cost = 1e300;
+    for (int cand = 64; cand >= 16; cand >>= 1) {
+      if (le && atoi(le) >= 1 && atoi(le) <= 64 && cand != atoi(le)) continue;
+      const double wgs = (double)ncases * (double)((h->base.num_chains + cand - 1) / cand);
+      double cost = wgs / slots;
+      if (cost < 1.0) cost = 1.0;
+      cost *= 1.0 + 0.1 * std::log2(cand / 16.0);
+      if (cost < best_cost) { best_cost = cost; best = cand; }
+    }
+    lanes = best;
+    A.lanes = lanes;
+    A.blocks_per_case = (h->base.num_chains + lanes - 1) / lanes;
+    if ((uint64_t)lanes * (uint64_t)h->base.n * PSTAT_CLUSTER_GM_CELL >= 0x80000000ull) {
+      pstat_destroy(h);
+      return fail(PSTAT_ERR_UNSUPPORTED, "num-monomers = %lld: a wave's working buffer must stay below 2 GiB",
+                  (long long)cases[0].n);
+    }
+  }
   if (stream) {
     h->stream = (hipStream_t)stream;
   } else {
@@ -381,7 +412,9 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_TRY(alloc(h, (void **)&S.nanrej, Cz * sizeof(int64_t)));
   const size_t nstate = h->bufs.size();
   CREATE_TRY(alloc(h, &S.ang_tmp, 2 * n * Cz * h->elem));
-  if (h->cfg.state_global)   // working copy of the cells, [chain block][n][64] double2 (run_segment, ST = 2)
+  if (cluster_gm)            // working copy of the chains, [chain block][lane][n] 48-byte cells (pstat_cluster_gm.hip)
+    CREATE_TRY(alloc(h, &S.work, cluster_gm_work_bytes(A)));
+  else if (h->cfg.state_global)   // working copy of the cells, [chain block][n][64] double2 (run_segment, ST = 2)
     CREATE_TRY(alloc(h, &S.work, (size_t)(A.blocks_per_case * ncases) * n * 64 * 16));
   CREATE_TRY(alloc(h, (void **)&h->d_cases, sizeof(CaseConst) * (size_t)ncases));
   CREATE_TRY(alloc(h, (void **)&h->d_queue, sizeof(int) * sweep_queue_ints(h->args)));

@@ -24,23 +24,13 @@
 
 #include <type_traits>
 
+#include "pstat_cluster_common.h"
 #include "pstat_device.h"
 #include "pstat_math.h"
 
 namespace pstat {
 
 namespace {
-
-template <typename R> struct V3 { R x, y, z; };
-template <typename R> __device__ __forceinline__ R dot3(const V3<R> &a, const V3<R> &b) {
-  return a.x * b.x + a.y * b.y + a.z * b.z;
-}
-// (acos_r: pstat_math.h)
-
-// psi_j, inc/eap_chain.jl:45-47
-template <typename R> __device__ __forceinline__ R bond_angle(const V3<R> &a, const V3<R> &b) {
-  return acos_r(fmin((R)1, fmax((R)-1, dot3(a, b))));
-}
 
 // ST = 0: the LDS cell is the (theta, phi) pair in R.  ST = 1 (PSTAT_Q16, R = float): one 32-bit word,
 // theta lattice index in the low half and phi index in the high half (pstat_math.h); the reflection
@@ -555,6 +545,7 @@ static int cluster_lds_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
 
 hipError_t cluster_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes, int *blocks_per_cu,
                                const char **name) {
+  if (cfg.state_global) return cluster_gm_kernel_info(cfg, a, lds_bytes, blocks_per_cu, name);   // pstat_cluster_gm.hip
   ClusterFn fn = pick_cluster(cfg);
   const int lds = cluster_lds_bytes(cfg, a);
   hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -571,6 +562,7 @@ hipError_t cluster_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *ld
 
 hipError_t launch_cluster(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s, const CaseConst *cases,
                           int *queue, unsigned grid, hipStream_t stream) {
+  if (cfg.state_global) return launch_cluster_gm(cfg, a, s, cases, queue, grid, stream);
   ClusterFn fn = pick_cluster(cfg);
   const int lds = cluster_lds_bytes(cfg, a);
   hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -37,9 +37,10 @@ struct DevState {
   double *uref;         // f64[C]         sum(u) of the chain's first configuration: the umbrella weights
                         //                are taken relative to it (a per-chain constant factor cancels
                         //                in value/normalizer, inc/average.jl:38,63-67)
-  void *work;           // f64 "global state" sweep only: the wave's working copy of its chains' (theta, phi) cells,
-                        //                [chain block][n][64] double2, random-accessed through L2 / Infinity Cache while a
-                        //                segment runs (filled from / spilled to `ang` like LDS is); not checkpointed
+  void *work;           // f64 "state in memory" kernels only: the waves' working copy of their chains while a segment
+                        //                runs (filled from / spilled to `ang` like LDS is); not checkpointed.  Sweep:
+                        //                [chain block][n][64] double2 (theta, phi).  Clustering main: [chain block][lane][n]
+                        //                48-byte cells (pstat_cluster_gm.hip)
   int64_t *nanrej;      // i64[C]         proposals whose trial energy was NaN or +-Inf (1/r^3 singularities of the
                         //                pair energies; the reference rejects them silently, inc/acceptance.jl:29-39)
   int64_t C;
@@ -254,7 +255,7 @@ struct LaunchCfg {
   int lag;  // a re-init has happened on this handle
   int rng;  // PSTAT_RNG_MWC64X | PSTAT_RNG_XOSHIRO128PP
   int move_set;  // PSTAT_MOVES_SINGLE (mcmc_eap_chain.jl) | PSTAT_MOVES_CLUSTER (mcmc_clustering_eap_chain.jl)
-  int state_global;  // f64 sweep: state cells in the global working buffer (DevState::work) instead of LDS
+  int state_global;  // f64 chain-per-lane kernels: state cells in the global working buffer (DevState::work) instead of LDS
 };
 hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                        const CaseConst *cases, double phi_step, double theta_step,
@@ -265,6 +266,12 @@ hipError_t launch_cluster(const LaunchCfg &cfg, const SweepArgs &a, const DevSta
                           const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream);
 hipError_t cluster_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
                                int *blocks_per_cu, const char **name);
+// the f64 cluster kernel with its chains in DevState::work (pstat_cluster_gm.hip); chosen by f64_state_global()
+hipError_t launch_cluster_gm(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
+                             const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream);
+hipError_t cluster_gm_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
+                                  int *blocks_per_cu, const char **name);
+size_t cluster_gm_work_bytes(const SweepArgs &a);
 hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                         const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream);
 size_t sweep_queue_ints(const SweepArgs &a);
@@ -281,7 +288,7 @@ size_t reduce_scratch_doubles();
 hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
                              int *blocks_per_cu, const char **name);
 int choose_lanes(int precision, int64_t n, int energy_type);
-bool f64_state_global(const LaunchCfg &cfg, int64_t n);   // the f64 sweep of this configuration keeps its state in DevState::work
+bool f64_state_global(const LaunchCfg &cfg, int64_t n);   // the f64 chain-per-lane kernel of this configuration keeps its state in DevState::work
 // --energy-type interacting: one chain per wavefront (pstat_interacting.hip), n <= 256
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                               const CaseConst *cases, int reinit_mode, hipStream_t stream);

@@ -26,6 +26,21 @@ def ps():
     return ps
 
 
+@pytest.fixture(params=["lds", "memory"])
+def f64_home(request, monkeypatch):
+    """Where the f64 chain-per-lane cluster kernel keeps a chain while a segment runs: (theta, phi) cells in LDS
+    (pstat_cluster.hip) or 48-byte cells with the reference's trigonometric cache in device memory
+    (pstat_cluster_gm.hip; the default for n > 40).  Every f64 parity test below runs on both."""
+    monkeypatch.setenv("PSTAT_F64_STATE", "global" if request.param == "memory" else "lds")
+    return request.param
+
+
+def _check_home(e, home):
+    k = e.launch_info().kernel.decode()
+    if "cluster_kernel<double" in k and home is not None:
+        assert ("state in memory" in k) == (home == "memory"), (k, home)
+
+
 def _pair(ps, nsteps, nchains, precision, burn_sched=(), burn_in=0, **kw):
     op, pp = both(nsteps, num_chains=nchains, precision=precision, **kw)
     if burn_sched:
@@ -52,9 +67,10 @@ def _run_gpu(e, pp, nsteps, burn_sched=(), burn_in=0):
     e.sync()
 
 
-def _bit_parity(ps, oracle, nsteps, nchains, burn_sched=(), burn_in=0, **kw):
+def _bit_parity(ps, oracle, nsteps, nchains, burn_sched=(), burn_in=0, home=None, **kw):
     op, pp = _pair(ps, nsteps, nchains, ps.F64, burn_sched, burn_in, **kw)
     with ps.Ensemble(pp) as e:
+        _check_home(e, home)
         _run_gpu(e, pp, nsteps, burn_sched, burn_in)
         for c in range(nchains):
             o = oracle.run(op, chain_id=c, mode="cluster", trace=True)
@@ -72,45 +88,49 @@ def _bit_parity(ps, oracle, nsteps, nchains, burn_sched=(), burn_in=0, **kw):
 
 
 @pytest.mark.parametrize("rng", [0, 1])
-def test_f64_bit_parity_cluster_dielectric(ps, oracle, rng):
+def test_f64_bit_parity_cluster_dielectric(ps, oracle, rng, f64_home):
     # BASELINE configs[4] family: bending stiffness + cluster flips, adaptation active
-    _bit_parity(ps, oracle, 6000, 66, n=20, E0=1.2, K1=1.0, K2=0.2, Fz=0.7, kT=1.0, seed=21, rng=rng,
+    _bit_parity(ps, oracle, 6000, 66, home=f64_home, n=20, E0=1.2, K1=1.0, K2=0.2, Fz=0.7, kT=1.0, seed=21, rng=rng,
                 bend_mod=0.5, bend_angle=0.3, cluster_prob=0.5, steps_per_adjust=500)
 
 
-def test_f64_bit_parity_cluster_polar_fx(ps, oracle):
-    _bit_parity(ps, oracle, 4000, 64, n=17, E0=0.8, mu=0.9, Fz=0.3, Fx=0.25, kT=0.8, b=1.2, chain_type=1,
+def test_f64_bit_parity_cluster_polar_fx(ps, oracle, f64_home):
+    _bit_parity(ps, oracle, 4000, 64, home=f64_home, n=17, E0=0.8, mu=0.9, Fz=0.3, Fx=0.25, kT=0.8, b=1.2, chain_type=1,
                 seed=22, bend_mod=0.2, bend_angle=0.0, cluster_prob=0.3, steps_per_adjust=400)
 
 
-def test_f64_bit_parity_cluster_ising(ps, oracle):
+def test_f64_bit_parity_cluster_ising(ps, oracle, f64_home):
     # Weak coupling and a short run on purpose: under the reference's Ising energy a reflected cluster
     # end can land anti-parallel to its neighbour, r = x_i - x_{i+1} -> 0 and U -> -1e7 within a few
     # thousand steps (polar chains at any coupling).  In that collapsed state a 1e-12 relative
     # difference in r (cumsum positions vs. b/2 (n_i + n_j)) already moves accept decisions, so
     # bit parity is only meaningful before the collapse.
-    _bit_parity(ps, oracle, 2000, 64, n=17, E0=1.0, K1=0.3, K2=0.02, Fz=0.3, Fx=0.25, kT=0.8, b=1.2,
+    _bit_parity(ps, oracle, 2000, 64, home=f64_home, n=17, E0=1.0, K1=0.3, K2=0.02, Fz=0.3, Fx=0.25, kT=0.8, b=1.2,
                 energy_type=2, seed=22, bend_mod=0.2, bend_angle=0.0, cluster_prob=0.3, steps_per_adjust=400)
 
 
-def test_f64_bit_parity_cluster_always_and_never(ps, oracle):
+def test_f64_bit_parity_cluster_always_and_never(ps, oracle, f64_home):
     # cluster_prob = 0: a cluster flip rides on every proposal; = 1: never (the plain single move + bending)
-    _bit_parity(ps, oracle, 3000, 64, n=12, E0=1.0, Fz=0.5, seed=23, cluster_prob=0.0, steps_per_adjust=300)
-    _bit_parity(ps, oracle, 3000, 64, n=12, E0=1.0, Fz=0.5, seed=23, cluster_prob=1.0, bend_mod=1.0,
+    _bit_parity(ps, oracle, 3000, 64, home=f64_home, n=12, E0=1.0, Fz=0.5, seed=23, cluster_prob=0.0, steps_per_adjust=300)
+    _bit_parity(ps, oracle, 3000, 64, home=f64_home, n=12, E0=1.0, Fz=0.5, seed=23, cluster_prob=1.0, bend_mod=1.0,
                 bend_angle=0.5, steps_per_adjust=300)
-    _bit_parity(ps, oracle, 2000, 64, n=2, E0=1.0, Fz=0.5, seed=24, cluster_prob=0.2)
+    _bit_parity(ps, oracle, 2000, 64, home=f64_home, n=2, E0=1.0, Fz=0.5, seed=24, cluster_prob=0.2)
+    # aligned start, no field: every link joins with probability ~1, so clusters run to the chain ends (many growth
+    # rounds, several member passes in the commit)
+    _bit_parity(ps, oracle, 1500, 64, home=f64_home, n=37, E0=0.2, Fz=0.1, seed=29, cluster_prob=0.1, use_x0=1, x0_phi=0.3,
+                x0_theta=0.4, dx0_phi=0.05, dx0_theta=0.05, steps_per_adjust=300)
 
 
-def test_f64_bit_parity_burn_in_ladder_and_x0(ps, oracle):
+def test_f64_bit_parity_burn_in_ladder_and_x0(ps, oracle, f64_home):
     # the annealing ladder: each rung restarts step sizes / acceptor / averagers at kT * factor
-    _bit_parity(ps, oracle, 3000, 64, burn_sched=(10.0, 2.0, 1.0), burn_in=1500, n=16, E0=1.0, Fz=0.6, kT=0.9,
+    _bit_parity(ps, oracle, 3000, 64, burn_sched=(10.0, 2.0, 1.0), burn_in=1500, home=f64_home, n=16, E0=1.0, Fz=0.6, kT=0.9,
                 seed=25, bend_mod=0.3, cluster_prob=0.5, steps_per_adjust=500)
     # --x0 "[phi; theta]" --dx0: start near a given orientation instead of uniformly
-    _bit_parity(ps, oracle, 2000, 64, n=16, E0=1.0, Fz=0.6, seed=26, cluster_prob=0.5, use_x0=1, x0_phi=0.3,
+    _bit_parity(ps, oracle, 2000, 64, home=f64_home, n=16, E0=1.0, Fz=0.6, seed=26, cluster_prob=0.5, use_x0=1, x0_phi=0.3,
                 x0_theta=1.2, dx0_phi=2 * np.pi, dx0_theta=0.1)
 
 
-def test_f64_bit_parity_per_monomer_x0(ps, oracle):
+def test_f64_bit_parity_per_monomer_x0(ps, oracle, f64_home):
     """--x0 of length 2n: [phi1, theta1, phi2, theta2, ...] + Uniform(0, dx0) (inc/eap_chain.jl:73-75), for the
     chain-per-lane kernel and the chain-per-wavefront one."""
     for n, extra in ((11, {}), (9, dict(energy_type=1, K1=0.5))):
@@ -121,6 +141,7 @@ def test_f64_bit_parity_per_monomer_x0(ps, oracle):
         from oracle import binding as ob
         op = ob.make_params(num_steps=800, x0_vec=x0, **kw)
         with ps.Ensemble(pp) as e:
+            _check_home(e, f64_home)
             e.advance(50)                                   # whatever happened before is discarded
             e.restart_from_x0(x0, 0.4, 0.05)
             g0 = e.chain_state(3)
@@ -137,8 +158,8 @@ def test_f64_bit_parity_per_monomer_x0(ps, oracle):
                 e.restart_from_x0(x0[:5], 0.4, 0.05)
 
 
-def test_f64_bit_parity_cluster_umbrella(ps, oracle):
-    _bit_parity(ps, oracle, 3000, 64, n=14, E0=1.5, K1=1.0, K2=0.0, Fz=0.2, seed=27, umbrella=1,
+def test_f64_bit_parity_cluster_umbrella(ps, oracle, f64_home):
+    _bit_parity(ps, oracle, 3000, 64, home=f64_home, n=14, E0=1.5, K1=1.0, K2=0.0, Fz=0.2, seed=27, umbrella=1,
                 bend_mod=0.4, bend_angle=0.2, cluster_prob=0.5, steps_per_adjust=500)
 
 
@@ -316,7 +337,7 @@ def test_scale_kT_is_a_ladder_rung_for_every_case(ps):
             a.scale_kT(0.0)
 
 
-def test_f64_bit_parity_random_cluster_configurations(ps, oracle):
+def test_f64_bit_parity_random_cluster_configurations(ps, oracle, f64_home):
     """Seeded fuzz over the clustering main's options (all four energies, bending, cluster_prob, ladder,
     both forms of --x0, umbrella, generator): the device trajectory equals the oracle's bit for bit."""
     rng = np.random.default_rng(20260502)
@@ -345,6 +366,7 @@ def test_f64_bit_parity_random_cluster_configurations(ps, oracle):
             op = ob.make_params(num_steps=nsteps, x0_vec=x0, dx0_phi=0.7, dx0_theta=0.1, burn_in=burn,
                                 burn_sched=list(sched), **kw)
         with ps.Ensemble(pp) as e:
+            _check_home(e, f64_home)
             if x0 is not None:
                 e.restart_from_x0(x0, 0.7, 0.1)
             _run_gpu(e, pp, nsteps, sched, burn)
@@ -354,3 +376,67 @@ def test_f64_bit_parity_random_cluster_configurations(ps, oracle):
                 assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (trial, kw, sched, x0mode)
                 assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total, (trial, kw)
                 np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-8, atol=1e-8, err_msg=str((trial, kw)))
+
+
+@pytest.mark.parametrize("n,kw", [
+    (100, dict(E0=1.0, K1=0.0, K2=1.0, Fz=0.0, adj_ub=0.40)),                       # run/Ising_2025-12-18.jl's chain, no coupling
+    (100, dict(E0=1.0, K1=0.3, K2=0.05, Fz=0.2, energy_type=2, bend_mod=0.3, bend_angle=0.2)),
+    (200, dict(E0=0.6, K1=0.25, K2=0.0, Fz=0.0, kT=2.5, energy_type=2, adj_ub=0.40)),   # a point of run/K1_E0-kT-phase.jl's grid
+    (41, dict(E0=1.0, mu=0.2, chain_type=1, Fz=0.4, Fx=0.3, energy_type=2, umbrella=1, rng=1)),
+])
+def test_f64_cluster_long_chains_bit_parity_in_the_default_home(ps, oracle, n, kw):
+    """The chain lengths the reference's sweeps launch this main with (n = 100, 200) run with the chains in device
+    memory by default (n > 40): trajectories against the oracle's literal clustering main, 70 chains = one full and one
+    6-lane wave, a launch split included (weak coupling: no 1/r^3 collapse in 1200 steps)."""
+    nsteps = 1200
+    op, pp = _pair(ps, nsteps, 70, ps.F64, n=n, seed=71, cluster_prob=0.5, steps_per_adjust=400, **kw)
+    with ps.Ensemble(pp) as e:
+        assert "state in memory" in e.launch_info().kernel.decode()
+        e.advance(500); e.advance(nsteps - 500)
+        e.sync()
+        for c in (0, 1, 31, 63, 64, 69):
+            o = oracle.run(op, chain_id=c, mode="cluster", trace=True)
+            g = e.chain_state(c)
+            assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (n, c)
+            assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total
+            assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step
+            np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(e.microstate(c), np.r_[o.r, o.p, o.U], rtol=1e-9, atol=1e-8)
+
+
+def test_f64_cluster_state_in_memory_matches_state_in_lds(ps, monkeypatch):
+    """Two homes for a chain, one step: forced either way, every compared chain's angles, generator, counters and step
+    sizes are bit-identical, the running sums agree to 1e-10 (a reflected monomer's cached n-hat is the mapped one, the
+    LDS kernel's is recomputed from the reflected angle: an ulp), also across launch splits, an annealing rung and a
+    checkpoint written by one variant and restored into the other."""
+    for kw in (dict(n=100, E0=1.0, K1=0.0, K2=1.0, adj_ub=0.40),
+               dict(n=17, E0=0.5, mu=0.7, Fz=0.3, Fx=0.4, chain_type=ps.POLAR, bend_mod=0.4, bend_angle=0.3, umbrella=1),
+               dict(n=64, E0=1.0, K1=0.3, K2=0.05, Fz=0.3, Fx=0.2, energy_type=ps.ISING, cluster_prob=0.2),
+               dict(n=33, E0=0.2, Fz=0.1, cluster_prob=0.1, use_x0=1, x0_phi=0.3, x0_theta=0.4, dx0_phi=0.05, dx0_theta=0.05)):
+        res, blob = {}, None
+        for where in ("lds", "global"):
+            monkeypatch.setenv("PSTAT_F64_STATE", where)
+            pp = ps.default_params(num_chains=200, precision=ps.F64, seed=78, steps_per_adjust=300,
+                                   move_set=ps.MOVES_CLUSTER, **kw)
+            with ps.Ensemble(pp) as e:
+                assert ("state in memory" in e.launch_info().kernel.decode()) == (where == "global")
+                e.scale_kT(3.0); e.advance(400)
+                e.scale_kT(1.0); e.reset_sampler(); e.reset_averages()
+                e.advance(501)
+                if blob is None:
+                    blob = e.checkpoint()
+                else:
+                    e.restore(blob)          # the other variant's checkpoint: the layout is the angles-only one
+                e.advance(299)
+                res[where] = [e.chain_state(c) for c in (0, 63, 64, 199)] + [e.reduce_host()]
+        for x, y in zip(res["lds"][:-1], res["global"][:-1]):
+            for key in ("theta", "phi", "rng"):
+                assert np.array_equal(x[key], y[key]), (kw, key)
+            np.testing.assert_allclose(x["sums"], y["sums"], rtol=1e-10, atol=1e-8)
+            assert (x["nacc_total"], x["phi_step"], x["theta_step"]) == (y["nacc_total"], y["phi_step"], y["theta_step"])
+            np.testing.assert_allclose(x["normalizer"], y["normalizer"], rtol=1e-12)
+        np.testing.assert_allclose(res["lds"][-1], res["global"][-1], rtol=1e-10, atol=1e-8)
+    monkeypatch.delenv("PSTAT_F64_STATE")
+    for n, mem in ((40, False), (41, True)):     # LDS seats four full waves per CU up to n = 40
+        with ps.Ensemble(ps.default_params(num_chains=64, precision=ps.F64, n=n, move_set=ps.MOVES_CLUSTER)) as e:
+            assert ("state in memory" in e.launch_info().kernel.decode()) == mem
