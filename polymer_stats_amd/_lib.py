@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpstat.so")
+# PSTAT_LIB: another build of the same library (kernel experiments: tools/build_variant.sh); never needed in production
+LIB_PATH = os.environ.get("PSTAT_LIB") or os.path.join(HERE, "libpstat.so")
 
 DIELECTRIC, POLAR = 0, 1
 NONINTERACTING, INTERACTING, ISING, CUTOFF = 0, 1, 2, 3

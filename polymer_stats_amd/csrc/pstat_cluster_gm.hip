@@ -39,7 +39,26 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2dd __attribute__((ext_vector_type(2)));
 
+#ifndef PSTAT_GM_LDAUX
+#define PSTAT_GM_LDAUX 0   // cache-policy bits of the working buffer's loads / stores (sc0 = 1, nt = 2, sc1 = 16)
+#endif
+#ifndef PSTAT_GM_STAUX
+#define PSTAT_GM_STAUX 0
+#endif
 constexpr uint32_t CELL = PSTAT_CLUSTER_GM_CELL;   // bytes per monomer
+#ifndef PSTAT_GM_W
+#define PSTAT_GM_W 3
+#endif
+#ifndef PSTAT_GM_E
+#define PSTAT_GM_E 4
+#endif
+#ifndef PSTAT_GM_XREQ
+#define PSTAT_GM_XREQ 1
+#endif
+constexpr int W = PSTAT_GM_W;        // rows on either side of the moved monomer that every step requests up front
+constexpr int E = PSTAT_GM_E;        // further rows, requested after growth round XREQ by the ends still growing then
+constexpr int XREQ = PSTAT_GM_XREQ;
+static_assert(XREQ < W, "the outer rows are requested inside the window rounds");
 constexpr uint32_t OOB = 0x80000000u;  // past every working buffer (num_records < 2^31, checked by the host): no access
 
 template <typename G, int CT, int EN>
@@ -69,11 +88,11 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wbase, 0, (int)((uint32_t)lanes * chain_bytes), 0x00020000);
   const uint32_t lb = (uint32_t)lane * chain_bytes;
   auto ld = [&](const uint32_t off) __attribute__((always_inline)) -> v2dd {
-    return __builtin_bit_cast(v2dd, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    return __builtin_bit_cast(v2dd, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, PSTAT_GM_LDAUX));
   };
   auto st = [&](const uint32_t off, const R x, const R y) __attribute__((always_inline)) {
     const v2dd v = {x, y};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), rsrc, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), rsrc, off, 0, PSTAT_GM_STAUX);
   };
   auto row_off = [&](const int row) __attribute__((always_inline)) -> uint32_t { return lb + (uint32_t)row * CELL; };
 
@@ -112,9 +131,8 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
   const R wscale = umb ? (0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT : 0.0;
   const R uref = umb ? S.uref[c] : 0.0;
   double wnorm = umb ? S.wnorm[c] : 0.0;
-  double sums[NSUMS];
-#pragma unroll
-  for (int q = 0; q < NSUMS; ++q) sums[q] = S.sums[q * C + c];
+  // (the f64 running sums stay in HBM: a block of FLUSH steps is added to them at a time -- 32 registers that the
+  // step's window needs more)
   const R inv_nm1 = n > 1 ? 1.0 / (double)(n - 1) : 0.0;
   const R ninv_kT = -1.0 / kT;
 
@@ -156,6 +174,13 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
     else epair = 0;
   };
 
+  auto up_off = [&](const int row, const bool want) __attribute__((always_inline)) -> uint32_t {
+    return (want && row <= n - 1) ? row_off(row) : OOB;
+  };
+  auto dn_off = [&](const int row, const bool want) __attribute__((always_inline)) -> uint32_t {
+    return (want && row >= 0) ? row_off(row) : OOB;
+  };
+
   while (left > 0) {
     int chunk = left < FLUSH ? left : FLUSH;
     if (A.adaptive && to_adj < chunk) chunk = (int)to_adj;
@@ -169,24 +194,29 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       const uint32_t wphi = g.next(), wth = g.next();
       const bool flipped = !(u01<R>(g.next()) <= cprob);
       const bool hasL = idx > 0, hasR = idx + 1 < n;
-      // ---- every row whose address follows from them.  At a chain end the missing neighbour's slot re-reads the
-      // monomer itself and its bond is masked out; rows past the chain, and the outer rows of lanes that grow no
-      // cluster, are steered off the buffer.
+      // ---- the WINDOW: the moved monomer and W rows on either side, requested at once and kept in registers for the
+      // whole step.  The single move's bonds, the first W growth rounds, the boundary bonds and the members' cells of
+      // 7 clusters in 8 come out of it.  At a chain end the missing neighbour's slot re-reads the monomer itself (its
+      // bond is masked out); rows past the chain, and the outer rows of lanes that grow no cluster, are steered off
+      // the buffer.  Rows W + 1 .. W + E (`x*`) follow after growth round XREQ, asked for by the ends still growing
+      // then (one in four), and serve rounds W .. W + E - 1 the same way.
       const uint32_t off0 = row_off(idx);
       const v2dd c0a = ld(off0), c0b = ld(off0 + 16), c0c = ld(off0 + 32);
-      const uint32_t offL = hasL ? off0 - CELL : off0, offR = hasR ? off0 + CELL : off0;
-      const v2dd La = ld(offL), Lb = ld(offL + 16), Ra = ld(offR), Rb = ld(offR + 16);
-      auto up_off = [&](const int row, const bool want) __attribute__((always_inline)) -> uint32_t {
-        return (want && row <= n - 1) ? row_off(row) : OOB;
-      };
-      auto dn_off = [&](const int row, const bool want) __attribute__((always_inline)) -> uint32_t {
-        return (want && row >= 0) ? row_off(row) : OOB;
-      };
-      uint32_t o;
-      o = up_off(idx + 2, flipped); v2dd Xua = ld(o), Xub = ld(o + 16);
-      o = dn_off(idx - 2, flipped); v2dd Xla = ld(o), Xlb = ld(o + 16);
-      o = up_off(idx + 3, flipped); v2dd Yua = ld(o), Yub = ld(o + 16);
-      o = dn_off(idx - 3, flipped); v2dd Yla = ld(o), Ylb = ld(o + 16);
+      v2dd ua[W + E + 1], ub[W + E + 1], da[W + E + 1], db[W + E + 1];   // [k]: row idx + k / idx - k (a = n_x, n_y; b = n_z, theta)
+      {
+        const uint32_t offR = hasR ? off0 + CELL : off0, offL = hasL ? off0 - CELL : off0;
+        ua[1] = ld(offR); ub[1] = ld(offR + 16);
+        da[1] = ld(offL); db[1] = ld(offL + 16);
+#pragma unroll
+        for (int k = 2; k <= W; ++k) {
+          uint32_t o = up_off(idx + k, flipped);
+          ua[k] = ld(o); ub[k] = ld(o + 16);
+          o = dn_off(idx - k, flipped);
+          da[k] = ld(o); db[k] = ld(o + 16);
+        }
+#pragma unroll
+        for (int k = W + 1; k <= W + E; ++k) { ua[k] = ub[k] = da[k] = db[k] = v2dd{0, 0}; }
+      }
 
       // ---- the single-monomer part
       const R th0 = c0b.y, ph0 = c0c.x, st0 = c0c.y;
@@ -199,12 +229,12 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       AG::sc_phi(ph1, &sp1, &cp1);
       const T3 n1{cp1 * st1, sp1 * st1, ct1};
       const T3 m0 = mu_of(n0), m1 = mu_of(n1);
-      const T3 nL{La.x, La.y, Lb.x}, nR{Ra.x, Ra.y, Rb.x};
+      auto nhat = [](const v2dd &a, const v2dd &b_) __attribute__((always_inline)) -> T3 { return T3{a.x, a.y, b_.x}; };
+      const T3 nL = nhat(da[1], db[1]), nR = nhat(ua[1], ub[1]);
       const T3 mL = mu_of(nL), mR = mu_of(nR);
-      const bool edgeL = is_edge(Lb.y) && hasL, edgeR = is_edge(Rb.y) && hasR;
 
       // ---- cluster_flip!(trial, idx), inc/eap_chain.jl:269-333 (see pstat_cluster.hip for the scheme: both ends grow
-      // in one loop of uniform rounds, each with its own draw while that end still grows)
+      // in one sequence of uniform rounds, each with its own draw while that end still grows)
       R alpha = 1;
       bool edge = false;
       int upper = idx, lower = idx;
@@ -213,65 +243,91 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       R snz = n1.z;                 // sums over the members (the moved monomer enters as proposed)
       T3 sm = m1;
       R upper_p = 0, lower_p = 0, new_upper_p = 0, new_lower_p = 0;
-      v2dd cua{0, 0}, cub{0, 0}, nua{0, 0}, nub{0, 0}, cla{0, 0}, clb{0, 0}, nla{0, 0}, nlb{0, 0};
-      v2dd mv[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+      T3 cu = n1, nu = nR, cl = n1, nl = nL;      // the monomers of the two boundary bonds
       const bool any_flip = __builtin_amdgcn_ballot_w64(flipped) != 0;   // wave-uniform
       if (any_flip) {
         edge = flipped && is_edge(th1);
-        T3 Au = n1, Bu = nR, Al = n1, Bl = nL;
-        bool eBu = edgeR, eBl = edgeL;
+        T3 Au = n1, Al = n1;
         bool gu = flipped && hasR, gl = flipped && hasL;
-        int rowu = idx + 3, rowl = idx - 3;   // the outermost rows requested so far
-        auto round = [&](v2dd &ua, v2dd &ub, v2dd &la, v2dd &lb_) __attribute__((always_inline)) {
-          const T3 Cu{ua.x, ua.y, ub.x}, Cl{la.x, la.y, lb_.x};
-          const bool eCu = is_edge(ub.y), eCl = is_edge(lb_.y);
-          rowu += 1; rowl -= 1;       // this register set is free again: request the row two rounds out
-          uint32_t q;
-          q = up_off(rowu, gu); ua = ld(q); ub = ld(q + 16);
-          q = dn_off(rowl, gl); la = ld(q); lb_ = ld(q + 16);
-          {
-            const R p = (1 + dot3(Au, Bu)) / 2;
-            G g2 = g;
-            const bool acc = gu && (u01<R>(g2.next()) <= p);
-            g.pick(gu, g2);
-            upper_p = gu ? p : upper_p;
-            upper += acc ? 1 : 0;
-            edge = edge || (acc && eBu);
-            member(acc, Bu, snz, sm);
-            gu = acc && upper < n - 1;
-            Au = Bu; Bu = Cu; eBu = eCu;
-          }
-          {
-            const R p = (1 + dot3(Al, Bl)) / 2;
-            G g2 = g;
-            const bool acc = gl && (u01<R>(g2.next()) <= p);
-            g.pick(gl, g2);
-            lower_p = gl ? p : lower_p;
-            lower -= acc ? 1 : 0;
-            edge = edge || (acc && eBl);
-            member(acc, Bl, snz, sm);
-            gl = acc && lower > 0;
-            Al = Bl; Bl = Cl; eBl = eCl;
-          }
+        // one end's link test of one round: A = the cluster's outermost member, B = the candidate beyond it
+        auto half_round = [&](const bool up, bool &gx, const T3 &A_, const T3 &B_, const bool eB, R &xp, int &ext)
+            __attribute__((always_inline)) {
+          const R p = (1 + dot3(A_, B_)) / 2;
+          G g2 = g;
+          const bool acc = gx && (u01<R>(g2.next()) <= p);
+          g.pick(gx, g2);
+          xp = gx ? p : xp;
+          ext += acc ? (up ? 1 : -1) : 0;
+          edge = edge || (acc && eB);
+          member(acc, B_, snz, sm);
+          gx = acc && (up ? ext < n - 1 : ext > 0);
         };
-        while (gu || gl) { round(Xua, Xub, Xla, Xlb); round(Yua, Yub, Yla, Ylb); }
+        // an end still growing when a round begins has (A, B) as its boundary bond unless it grows on: overwritten every
+        // round it is alive, the last one stays
+        auto capture = [&](const bool gx, const T3 &A_, const T3 &B_, T3 &c_, T3 &n_) __attribute__((always_inline)) {
+          c_.x = gx ? A_.x : c_.x; c_.y = gx ? A_.y : c_.y; c_.z = gx ? A_.z : c_.z;
+          n_.x = gx ? B_.x : n_.x; n_.y = gx ? B_.y : n_.y; n_.z = gx ? B_.z : n_.z;
+        };
+#pragma unroll
+        for (int t = 0; t < W; ++t) {      // rounds inside the window: link (idx + t, idx + t + 1), then (idx - t, idx - t - 1)
+          const T3 Bu = nhat(ua[t + 1], ub[t + 1]), Bl = nhat(da[t + 1], db[t + 1]);
+          half_round(true, gu, Au, Bu, is_edge(ub[t + 1].y) && (t > 0 || hasR), upper_p, upper);
+          Au = Bu;
+          half_round(false, gl, Al, Bl, is_edge(db[t + 1].y) && (t > 0 || hasL), lower_p, lower);
+          Al = Bl;
+          if (t == XREQ) {
+#pragma unroll
+            for (int k = W + 1; k <= W + E; ++k) {
+              uint32_t q = up_off(idx + k, gu);
+              ua[k] = ld(q); ub[k] = ld(q + 16);
+              q = dn_off(idx - k, gl);
+              da[k] = ld(q); db[k] = ld(q + 16);
+            }
+          }
+        }
+        // the boundary monomers of an end that stopped inside the window (ku accepted links: rows ku and ku + 1)
+        {
+          const int ku = upper - idx, kl = idx - lower;
+#pragma unroll
+          for (int k = 1; k < W; ++k) {
+            const T3 a_ = nhat(ua[k], ub[k]), a1_ = nhat(ua[k + 1], ub[k + 1]), b_ = nhat(da[k], db[k]), b1_ = nhat(da[k + 1], db[k + 1]);
+            capture(ku >= k, a_, a1_, cu, nu);
+            capture(kl >= k, b_, b1_, cl, nl);
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(gu || gl) != 0) {
+          // ---- rounds W .. W + E - 1, out of the rows requested after round XREQ
+#pragma unroll
+          for (int t = W; t < W + E; ++t) {
+            const T3 Bu = nhat(ua[t + 1], ub[t + 1]), Bl = nhat(da[t + 1], db[t + 1]);
+            capture(gu, Au, Bu, cu, nu);
+            half_round(true, gu, Au, Bu, is_edge(ub[t + 1].y), upper_p, upper);
+            Au = Bu;
+            capture(gl, Al, Bl, cl, nl);
+            half_round(false, gl, Al, Bl, is_edge(db[t + 1].y), lower_p, lower);
+            Al = Bl;
+          }
+          // ---- beyond: one end in 2^(W + E) gets here; a row per round, waited for
+          while (gu || gl) {
+            uint32_t q = up_off(upper + 1, gu);
+            const v2dd xa = ld(q), xb = ld(q + 16);
+            q = dn_off(lower - 1, gl);
+            const v2dd ya = ld(q), yb = ld(q + 16);
+            const T3 Bu = nhat(xa, xb), Bl = nhat(ya, yb);
+            capture(gu, Au, Bu, cu, nu);
+            half_round(true, gu, Au, Bu, is_edge(xb.y), upper_p, upper);
+            Au = gu ? Bu : Au;
+            capture(gl, Al, Bl, cl, nl);
+            half_round(false, gl, Al, Bl, is_edge(yb.y), lower_p, lower);
+            Al = gl ? Bl : Al;
+          }
+        }
         upper_p = upper >= n - 1 ? (R)0 : upper_p;   // ran into the chain end: no link to test, :282-284
         lower_p = lower <= 0 ? (R)0 : lower_p;       // :299-301
-        // the extents are known: request the monomers of the two boundary bonds (:318-326; the moved monomer enters as
-        // proposed) and the first four members, whose cells an accepted proposal rewrites
-        const bool selfu = upper == idx, selfl = lower == idx;
-        o = (flipped && !selfu) ? row_off(upper) : OOB; cua = ld(o); cub = ld(o + 16);
-        o = (flipped && upper < n - 1) ? row_off(upper + 1) : OOB; nua = ld(o); nub = ld(o + 16);
-        o = (flipped && !selfl) ? row_off(lower) : OOB; cla = ld(o); clb = ld(o + 16);
-        o = (flipped && lower > 0) ? row_off(lower - 1) : OOB; nla = ld(o); nlb = ld(o + 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int m = lower + j;
-          mv[j] = ld((flipped && m <= upper && m != idx) ? row_off(m) + 16 : OOB);
-        }
       }
+      const uint32_t weps = g.next();   // the acceptance draw comes after the cluster's draws
 
-      // ---- the single move's two bonds, before and after (they need nothing of the above: its loads land meanwhile)
+      // ---- the single move's two bonds, before and after
       const R du_field = mhalfE0 * (m1.z - m0.z);
       R dpsi = 0, dbend = 0, dpair = 0;
       {
@@ -288,12 +344,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       }
 
       if (any_flip) {
-        // the two boundary bonds, before and after the reflection
-        const bool selfu = upper == idx, selfl = lower == idx;
-        T3 cu{cua.x, cua.y, cub.x}, cl{cla.x, cla.y, clb.x};
-        const T3 nu{nua.x, nua.y, nub.x}, nl{nla.x, nla.y, nlb.x};
-        cu.x = selfu ? n1.x : cu.x; cu.y = selfu ? n1.y : cu.y; cu.z = selfu ? n1.z : cu.z;
-        cl.x = selfl ? n1.x : cl.x; cl.y = selfl ? n1.y : cl.y; cl.z = selfl ? n1.z : cl.z;
+        // the two boundary bonds, before and after the reflection (:318-326; the moved monomer enters as proposed)
         const T3 cum = mu_of(cu), clm = mu_of(cl), num = mu_of(nu), nlm = mu_of(nl);
         {
           const bool on = flipped && upper < n - 1;
@@ -321,7 +372,6 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
         if constexpr (CT == PSTAT_DIELECTRIC) { dp_flip.x = f2 * sm.x; dp_flip.y = f2 * sm.y; }
         else { dp_flip.z = f2 * sm.z; du_flip += mhalfE0 * dp_flip.z; }
       }
-      const uint32_t weps = g.next();   // the acceptance draw comes after the cluster's draws
 
       // ---- energy difference of the whole proposal, inc/energy.jl:7-23
       const R drx = b * (n1.x - n0.x), dry = b * (n1.y - n0.y), drz = b * (n1.z - n0.z) + drz_flip;
@@ -345,28 +395,41 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       // ---- commit: stores steered by address (a rejected proposal stores nothing)
       {
         const bool okf = ok && flipped;
+#ifdef PSTAT_GM_NOSTORE   // (timing experiment: nothing is ever committed to memory)
+        const uint32_t os = OOB;
+#else
         const uint32_t os = ok ? off0 : OOB;
+#endif
         st(os, n1.x, n1.y);
         st(os + 16, flipped ? -n1.z : n1.z, flipped ? refl_theta(th1) : th1);
         st(os + 32, ph1, st1);
         if (any_flip) {
+          // the members inside the window come out of its registers: n_z -> -n_z, theta reflected
+          const int ku = upper - idx, kl = idx - lower;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int m = lower + j;
-            st((okf && m <= upper && m != idx) ? row_off(m) + 16 : OOB, -mv[j].x, refl_theta(mv[j].y));
+          for (int k = 1; k <= W; ++k) {
+            st((okf && k <= ku) ? off0 + (uint32_t)k * CELL + 16 : OOB, -ub[k].x, refl_theta(ub[k].y));
+            st((okf && k <= kl) ? off0 - (uint32_t)k * CELL + 16 : OOB, -db[k].x, refl_theta(db[k].y));
           }
-          // longer clusters: four members per pass
-          for (int i = lower + 4; __builtin_amdgcn_ballot_w64(okf && i <= upper) != 0; i += 4) {
-            v2dd v[4];
+          if (__builtin_amdgcn_ballot_w64(okf && (ku > W || kl > W)) != 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int m = i + j;
-              v[j] = ld((okf && m <= upper && m != idx) ? row_off(m) + 16 : OOB);
+            for (int k = W + 1; k <= W + E; ++k) {
+              st((okf && k <= ku) ? off0 + (uint32_t)k * CELL + 16 : OOB, -ub[k].x, refl_theta(ub[k].y));
+              st((okf && k <= kl) ? off0 - (uint32_t)k * CELL + 16 : OOB, -db[k].x, refl_theta(db[k].y));
             }
+            // members beyond the requested rows: read-modify-write, two rows of either side per pass
+            for (int i = W + E + 1; __builtin_amdgcn_ballot_w64(okf && (i <= ku || i <= kl)) != 0; i += 2) {
+              v2dd v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int m = i + j;
-              st((okf && m <= upper && m != idx) ? row_off(m) + 16 : OOB, -v[j].x, refl_theta(v[j].y));
+              for (int j = 0; j < 2; ++j) {
+                v[j] = ld((okf && i + j <= ku) ? off0 + (uint32_t)(i + j) * CELL + 16 : OOB);
+                v[2 + j] = ld((okf && i + j <= kl) ? off0 - (uint32_t)(i + j) * CELL + 16 : OOB);
+              }
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                st((okf && i + j <= ku) ? off0 + (uint32_t)(i + j) * CELL + 16 : OOB, -v[j].x, refl_theta(v[j].y));
+                st((okf && i + j <= kl) ? off0 - (uint32_t)(i + j) * CELL + 16 : OOB, -v[2 + j].x, refl_theta(v[2 + j].y));
+              }
             }
           }
         }
@@ -395,12 +458,16 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       a2[6] = fma_r(wgt * OU, OU, a2[6]);
     }
 
-    sums[S_R1] += a1[0]; sums[S_R2] += a1[1]; sums[S_R3] += a1[2];
-    sums[S_P1] += a1[3]; sums[S_P2] += a1[4]; sums[S_P3] += a1[5];
-    sums[S_U] += a1[6]; sums[S_C2] += a1[7]; sums[S_PSI] += a1[8];
-    sums[S_R1SQ] += a2[0]; sums[S_R2SQ] += a2[1]; sums[S_R3SQ] += a2[2];
-    sums[S_P1SQ] += a2[3]; sums[S_P2SQ] += a2[4]; sums[S_P3SQ] += a2[5];
-    sums[S_USQ] += a2[6];
+    {
+      double *const sm_ = S.sums + c;
+      auto add = [&](const int q, const R v) __attribute__((always_inline)) { sm_[(int64_t)q * C] += v; };
+      add(S_R1, a1[0]); add(S_R2, a1[1]); add(S_R3, a1[2]);
+      add(S_P1, a1[3]); add(S_P2, a1[4]); add(S_P3, a1[5]);
+      add(S_U, a1[6]); add(S_C2, a1[7]); add(S_PSI, a1[8]);
+      add(S_R1SQ, a2[0]); add(S_R2SQ, a2[1]); add(S_R3SQ, a2[2]);
+      add(S_P1SQ, a2[3]); add(S_P2SQ, a2[4]); add(S_P3SQ, a2[5]);
+      add(S_USQ, a2[6]);
+    }
     wnorm += accw;
     step += chunk;
     left -= chunk;
@@ -448,8 +515,6 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
   S.obs[OBS_C2 * C + c] = c2sum; S.obs[OBS_PSI * C + c] = psisum;
   S.lag[c] = lag_pending ? log_r(lag_alpha) : lag;
   if (umb) S.wnorm[c] = wnorm;
-#pragma unroll
-  for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
 }
 
 template <typename G, int CT, int EN>
