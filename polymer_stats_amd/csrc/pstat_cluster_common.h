@@ -6,7 +6,9 @@
 
 #include "pstat_math.h"
 
+#ifndef PSTAT_CLUSTER_GM_CELL
 #define PSTAT_CLUSTER_GM_CELL 48u   // bytes per monomer of pstat_cluster_gm.hip's working buffer
+#endif
 
 namespace pstat {
 

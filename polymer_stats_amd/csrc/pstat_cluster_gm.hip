@@ -94,6 +94,14 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
     const v2dd v = {x, y};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), rsrc, off, 0, PSTAT_GM_STAUX);
   };
+  auto ld8 = [&](const uint32_t off) __attribute__((always_inline)) -> R {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, PSTAT_GM_LDAUX));
+  };
+  auto st8 = [&](const uint32_t off, const R x) __attribute__((always_inline)) {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, x), rsrc, off, 0, PSTAT_GM_STAUX);
+  };
   auto row_off = [&](const int row) __attribute__((always_inline)) -> uint32_t { return lb + (uint32_t)row * CELL; };
 
   // ---- fill: angles from the checkpoint planes (coalesced over the lanes), the cached trigonometry derived from them
@@ -109,7 +117,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       const uint32_t o = row_off(i);
       st(o, cp * s, sp * s);
       st(o + 16, co, th);
-      st(o + 32, ph, s);
+      if constexpr (CELL == 40) st8(o + 32, ph); else st(o + 32, ph, s);
     }
   }
   G g;
@@ -181,6 +189,13 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
     return (want && row >= 0) ? row_off(row) : OOB;
   };
 
+#ifdef PSTAT_GM_PROF   // (timing experiment: wave clocks of the step's phases, printed by one wave per launch)
+  uint64_t pf_t[6] = {0, 0, 0, 0, 0, 0};
+  auto pf_now = []() __attribute__((always_inline)) -> uint64_t { return __builtin_readcyclecounter(); };
+#define PF_MARK(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const uint64_t t_ = pf_now(); pf_t[i] += t_ - pf_last; pf_last = t_; } while (0)
+#else
+#define PF_MARK(i) do {} while (0)
+#endif
   while (left > 0) {
     int chunk = left < FLUSH ? left : FLUSH;
     if (A.adaptive && to_adj < chunk) chunk = (int)to_adj;
@@ -190,6 +205,9 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
     for (int s = 0; s < chunk; ++s) {
       // ---- every draw whose place in the stream is fixed: mcmc_clustering_eap_chain.jl:269-272 and the skip draw of
       // cluster_flip! (inc/eap_chain.jl:276)
+#ifdef PSTAT_GM_PROF
+      uint64_t pf_last = pf_now();
+#endif
       const int idx = (int)__umulhi(g.next(), (uint32_t)n);
       const uint32_t wphi = g.next(), wth = g.next();
       const bool flipped = !(u01<R>(g.next()) <= cprob);
@@ -201,7 +219,9 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       // the buffer.  Rows W + 1 .. W + E (`x*`) follow after growth round XREQ, asked for by the ends still growing
       // then (one in four), and serve rounds W .. W + E - 1 the same way.
       const uint32_t off0 = row_off(idx);
-      const v2dd c0a = ld(off0), c0b = ld(off0 + 16), c0c = ld(off0 + 32);
+      const v2dd c0a = ld(off0), c0b = ld(off0 + 16);
+      v2dd c0c;
+      if constexpr (CELL == 40) c0c = v2dd{ld8(off0 + 32), 0.0}; else c0c = ld(off0 + 32);
       v2dd ua[W + E + 1], ub[W + E + 1], da[W + E + 1], db[W + E + 1];   // [k]: row idx + k / idx - k (a = n_x, n_y; b = n_z, theta)
       {
         const uint32_t offR = hasR ? off0 + CELL : off0, offL = hasL ? off0 - CELL : off0;
@@ -218,8 +238,11 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
         for (int k = W + 1; k <= W + E; ++k) { ua[k] = ub[k] = da[k] = db[k] = v2dd{0, 0}; }
       }
 
+      PF_MARK(0);   // window requested and landed (behind the preceding commit's stores)
       // ---- the single-monomer part
-      const R th0 = c0b.y, ph0 = c0c.x, st0 = c0c.y;
+      const R th0 = c0b.y, ph0 = c0c.x;
+      R st0 = c0c.y;
+      if constexpr (CELL == 40) { R ct0_; AG::sc_theta(th0, &st0, &ct0_); }   // (40-byte cells carry no sin(theta))
       const T3 n0{c0a.x, c0a.y, c0b.x};
       const R ct0 = n0.z;
       const R ph1 = ph0 + phistep * sym11<R>(wphi);
@@ -326,6 +349,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
         lower_p = lower <= 0 ? (R)0 : lower_p;       // :299-301
       }
       const uint32_t weps = g.next();   // the acceptance draw comes after the cluster's draws
+      PF_MARK(1);   // single-move trigonometry + growth
 
       // ---- the single move's two bonds, before and after
       const R du_field = mhalfE0 * (m1.z - m0.z);
@@ -392,6 +416,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       ok = ok && !edge;
       if constexpr (EN == PSTAT_ISING) nnan_seg += not_finite(dU) ? 1 : 0;
 
+      PF_MARK(2);   // bonds + Metropolis
       // ---- commit: stores steered by address (a rejected proposal stores nothing)
       {
         const bool okf = ok && flipped;
@@ -402,7 +427,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
 #endif
         st(os, n1.x, n1.y);
         st(os + 16, flipped ? -n1.z : n1.z, flipped ? refl_theta(th1) : th1);
-        st(os + 32, ph1, st1);
+        if constexpr (CELL == 40) st8(os + 32, ph1); else st(os + 32, ph1, st1);
         if (any_flip) {
           // the members inside the window come out of its registers: n_z -> -n_z, theta reflected
           const int ku = upper - idx, kl = idx - lower;
@@ -446,6 +471,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
         nacc_seg += ok ? 1 : 0;
       }
 
+      PF_MARK(3);   // commit, its stores acknowledged
       // ---- record! x 10, mcmc_clustering_eap_chain.jl:243-244,310-311
       const R wgt = umb ? exp_r(-(usum - uref) * wscale) : (R)1;
       const R psim = psisum * inv_nm1;
@@ -456,6 +482,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       a2[0] = fma_r(wgt * Orx, Orx, a2[0]); a2[1] = fma_r(wgt * Ory, Ory, a2[1]); a2[2] = fma_r(wgt * Orz, Orz, a2[2]);
       a2[3] = fma_r(wgt * Opx, Opx, a2[3]); a2[4] = fma_r(wgt * Opy, Opy, a2[4]); a2[5] = fma_r(wgt * Opz, Opz, a2[5]);
       a2[6] = fma_r(wgt * OU, OU, a2[6]);
+      PF_MARK(4);   // record
     }
 
     {
@@ -493,13 +520,21 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
     }
   }
 
+#ifdef PSTAT_GM_PROF
+  if (blk == 3 && lane == 0 && remaining > 100)
+    printf("gm prof (cycles per step): window %.0f  move+growth %.0f  bonds+accept %.0f  commit %.0f  record %.0f\n",
+           (double)pf_t[0] / remaining, (double)pf_t[1] / remaining, (double)pf_t[2] / remaining, (double)pf_t[3] / remaining,
+           (double)pf_t[4] / remaining);
+#endif
   // ---- spill: the angles back to the checkpoint planes
   {
     R *gth = (R *)S.ang, *gph = (R *)S.ang + (int64_t)n * C;
 #pragma unroll 4
     for (int i = 0; i < n; ++i) {
       const uint32_t o = row_off(i);
-      const v2dd b1 = ld(o + 16), b2 = ld(o + 32);
+      const v2dd b1 = ld(o + 16);
+      v2dd b2;
+      if constexpr (CELL == 40) b2 = v2dd{ld8(o + 32), 0.0}; else b2 = ld(o + 32);
       gth[(int64_t)i * C + c] = b1.y;
       gph[(int64_t)i * C + c] = b2.x;
     }
