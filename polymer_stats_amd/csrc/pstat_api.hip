@@ -462,12 +462,12 @@ void pstat_destroy(pstat_handle *h) {
 
 // Splits a launch of `nsteps` steps into time segments so that blocks*segments fills the resident
 // workgroup slots evenly (see sweep_kernel).  Returns segments per block.
-static int choose_segments(int64_t blocks, int64_t slots, int64_t nsteps) {
-  if (blocks <= slots || nsteps < 4000) return 1;
+static int choose_segments(int64_t blocks, int64_t slots, int64_t nsteps, int64_t min_seg) {
+  if (blocks <= slots || nsteps < 2 * min_seg) return 1;
   int best = 1;
   double best_eff = 0;
   for (int s = 1; s <= 12; ++s) {
-    if (nsteps / s < 2000) break;                 // keep fill/spill amortised
+    if (nsteps / s < min_seg) break;              // keep fill/spill amortised
     const double jobs = (double)blocks * s;
     const double eff = jobs / (std::ceil(jobs / slots) * slots);   // busy fraction of the slots
     if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
@@ -503,7 +503,10 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
   const char *ms = getenv("PSTAT_MAX_SPINS");
   while (nsteps > 0) {
     const int64_t len = nsteps < max_launch ? nsteps : max_launch;
-    int nseg = env ? atoi(env) : choose_segments(blocks, h->slots, len);
+    // (a fill + spill of the f64 cluster kernel's working buffer costs about ten of its steps, the LDS kernels' a few
+    // hundred of theirs)
+    const bool cluster_gm = h->cfg.state_global && h->cfg.move_set == PSTAT_MOVES_CLUSTER;
+    int nseg = env ? atoi(env) : choose_segments(blocks, h->slots, len, cluster_gm ? 400 : 2000);
     if (nseg < 1) nseg = 1;
     // f32/q16 running totals are re-derived from the angles at every segment start: bound the stretch
     // over which their rounding errors can random-walk

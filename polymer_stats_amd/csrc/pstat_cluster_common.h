@@ -7,7 +7,7 @@
 #include "pstat_math.h"
 
 #ifndef PSTAT_CLUSTER_GM_CELL
-#define PSTAT_CLUSTER_GM_CELL 48u   // bytes per monomer of pstat_cluster_gm.hip's working buffer
+#define PSTAT_CLUSTER_GM_CELL 40u   // bytes per monomer of pstat_cluster_gm.hip's working buffer (40, or 48 with sin(theta) cached too)
 #endif
 
 namespace pstat {

@@ -6,24 +6,31 @@
 //   * An f64 (theta, phi) cell is 16 bytes, so LDS seats 160 KiB / (16 n) chains per CU: 102 at n = 100, 51 at n = 200 --
 //     a quarter (an eighth) of the 256 lanes of a CU's four SIMDs.  Here the cells live in DevState::work, laid out
 //     CHAIN-CONTIGUOUS, [chain block][lane][monomer], and every SIMD carries a full wave.  A proposal touches the moved
-//     monomer, its two neighbours and the monomers the cluster grows over -- one contiguous run of the chain, i.e. two
-//     or three 128-byte lines per proposal whatever the lane's random monomer index is.
-//   * A cell is the reference's own per-monomer cache (inc/eap_chain.jl:22-28: cphi, sphi, ctheta, stheta, n-hat), 48
-//     bytes: [n_x, n_y | n_z, theta | phi, sin(theta)].  The LDS kernel re-derives n-hat from the angles of every row it
-//     visits (two sincos per row: ~65 f64 instructions, ~50 rows per wave-step, two thirds of its instruction stream);
-//     LDS capacity forbade the cache there, device memory does not.  A reflection (refl_n!, inc/eap_chain.jl:263-265)
-//     maps a cached cell exactly: n_z -> -n_z, theta -> clamp(theta + (pi - 2 theta)), sin(theta) kept.  The reference
-//     recomputes sin and cos of the reflected angle, which agrees with the mapped values to an ulp or two (theta +
-//     (pi - 2 theta) is pi - theta rounded); that is the same class of difference as device sincos vs glibc (see
-//     sincos_fast_f64) and moves a decision with probability ~1e-9 per decision: the trajectories of the bit-parity
-//     tests are unchanged.  theta itself is stored and updated exactly as the reference does.
+//     monomer, its two neighbours and the monomers the cluster grows over -- one contiguous run of the chain, i.e. three
+//     or four 128-byte lines per proposal whatever the lane's random monomer index is.
+//   * A cell is the reference's own per-monomer cache (inc/eap_chain.jl:22-28: the trigonometry of every monomer is kept
+//     beside its angles), 40 bytes: [n_x, n_y | n_z, theta | phi].  The LDS kernel re-derives n-hat from the angles of
+//     every row it visits (two sincos per row: ~65 f64 instructions, ~50 rows per wave-step, two thirds of its
+//     instruction stream); LDS capacity forbade the cache there, device memory does not.  A reflection (refl_n!,
+//     inc/eap_chain.jl:263-265) maps a cached cell exactly: n_z -> -n_z, theta -> clamp(theta + (pi - 2 theta)).  The
+//     reference recomputes sin and cos of the reflected angle, which agrees with the mapped values to an ulp or two
+//     (theta + (pi - 2 theta) is pi - theta rounded); that is the same class of difference as device sincos vs glibc
+//     (see sincos_fast_f64): a link or Metropolis decision compares against a 23-bit uniform, so it moves with
+//     probability |delta p| ~ 1e-16 per decision.  theta itself is stored and updated exactly as the reference does.
+//     40 bytes and not 48 (with sin(theta)): 65 536 chains x 100 monomers are 262 MB against 315 MB, and the 256 MiB
+//     Infinity Cache decides the latency of every access (measured: +14 % at n = 100; a chain length whose working set
+//     fits entirely, n <= 72, runs another 10 % faster).
 //   * Loads and stores go through a buffer resource and are steered by ADDRESS: an offset past the buffer makes a load
-//     return 0 and drops a store, so speculative rows of lanes that do not grow, and the stores of rejected proposals,
-//     cost no traffic and no branch.
-//   * Order inside a step: all rows whose addresses are known from the draws (the moved monomer, its neighbours and two
-//     rows further out on either side) are requested at once; growth requests two rounds ahead; the cluster's boundary
-//     rows and its members (for the read-modify-write of an accepted reflection) are requested as soon as the extents
-//     are known and land while the single move's four bond terms are computed.
+//     return 0 and drops a store, so the rows of lanes that do not grow, and the stores of rejected proposals, cost no
+//     traffic and no branch.
+//   * The step is LATENCY-bound (a dependent access costs ~1 300 cycles from the Infinity Cache, ~3 000 from HBM, one wave
+//     per SIMD), so it is organised to have as few memory phases as possible: a WINDOW of the moved monomer and W rows on
+//     either side is requested at once and kept in registers for the whole step -- the single move's bonds, the first W
+//     growth rounds, the boundary bonds and the members' new cells of 7 clusters in 8 come out of it; the ends still
+//     growing after round XREQ (one in four) request E more rows, which serve the next E rounds the same way; only one
+//     end in 2^(W+E) goes on row by row.  An accepted reflection rewrites its members from those registers (no
+//     read-modify-write).  Requesting the next step's window a step ahead (with the commit forwarded into it) was built
+//     and measured: no gain, the forwarding costs what the latency saved.
 // HBM holds the checkpoint layout (DevState::ang, angles only); the working buffer is filled from it when a segment
 // starts and spilled to it when it ends, exactly as the LDS variants do.
 #include <hip/hip_runtime.h>
@@ -95,7 +102,6 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), rsrc, off, 0, PSTAT_GM_STAUX);
   };
   auto ld8 = [&](const uint32_t off) __attribute__((always_inline)) -> R {
-    typedef int v2i __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, PSTAT_GM_LDAUX));
   };
   auto st8 = [&](const uint32_t off, const R x) __attribute__((always_inline)) {
@@ -189,6 +195,32 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
     return (want && row >= 0) ? row_off(row) : OOB;
   };
 
+  // ---- the draws whose place in the stream is fixed (mcmc_clustering_eap_chain.jl:269-272 and the skip draw of
+  // cluster_flip!, inc/eap_chain.jl:276) and the WINDOW they address
+  struct Draw { int idx; uint32_t wphi, wth; bool flipped; };
+  struct Win { v2dd c0a, c0b, c0c, ua[W + 1], ub[W + 1], da[W + 1], db[W + 1]; };
+  auto draw_next = [&]() __attribute__((always_inline)) -> Draw {
+    Draw d;
+    d.idx = (int)__umulhi(g.next(), (uint32_t)n);
+    d.wphi = g.next(); d.wth = g.next();
+    d.flipped = !(u01<R>(g.next()) <= cprob);
+    return d;
+  };
+  auto request = [&](const Draw &d, Win &w) __attribute__((always_inline)) {
+    const uint32_t off0 = row_off(d.idx);
+    w.c0a = ld(off0); w.c0b = ld(off0 + 16);
+    if constexpr (CELL == 40) w.c0c = v2dd{ld8(off0 + 32), 0.0}; else w.c0c = ld(off0 + 32);
+    const uint32_t offR = d.idx + 1 < n ? off0 + CELL : off0, offL = d.idx > 0 ? off0 - CELL : off0;
+    w.ua[1] = ld(offR); w.ub[1] = ld(offR + 16);
+    w.da[1] = ld(offL); w.db[1] = ld(offL + 16);
+#pragma unroll
+    for (int k = 2; k <= W; ++k) {
+      uint32_t o = up_off(d.idx + k, d.flipped);
+      w.ua[k] = ld(o); w.ub[k] = ld(o + 16);
+      o = dn_off(d.idx - k, d.flipped);
+      w.da[k] = ld(o); w.db[k] = ld(o + 16);
+    }
+  };
 #ifdef PSTAT_GM_PROF   // (timing experiment: wave clocks of the step's phases, printed by one wave per launch)
   uint64_t pf_t[6] = {0, 0, 0, 0, 0, 0};
   auto pf_now = []() __attribute__((always_inline)) -> uint64_t { return __builtin_readcyclecounter(); };
@@ -205,12 +237,15 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
     for (int s = 0; s < chunk; ++s) {
       // ---- every draw whose place in the stream is fixed: mcmc_clustering_eap_chain.jl:269-272 and the skip draw of
       // cluster_flip! (inc/eap_chain.jl:276)
+      const Draw d = draw_next();
+      Win w;
+      request(d, w);
 #ifdef PSTAT_GM_PROF
       uint64_t pf_last = pf_now();
 #endif
-      const int idx = (int)__umulhi(g.next(), (uint32_t)n);
-      const uint32_t wphi = g.next(), wth = g.next();
-      const bool flipped = !(u01<R>(g.next()) <= cprob);
+      const int idx = d.idx;
+      const uint32_t wphi = d.wphi, wth = d.wth;
+      const bool flipped = d.flipped;
       const bool hasL = idx > 0, hasR = idx + 1 < n;
       // ---- the WINDOW: the moved monomer and W rows on either side, requested at once and kept in registers for the
       // whole step.  The single move's bonds, the first W growth rounds, the boundary bonds and the members' cells of
@@ -219,24 +254,12 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       // the buffer.  Rows W + 1 .. W + E (`x*`) follow after growth round XREQ, asked for by the ends still growing
       // then (one in four), and serve rounds W .. W + E - 1 the same way.
       const uint32_t off0 = row_off(idx);
-      const v2dd c0a = ld(off0), c0b = ld(off0 + 16);
-      v2dd c0c;
-      if constexpr (CELL == 40) c0c = v2dd{ld8(off0 + 32), 0.0}; else c0c = ld(off0 + 32);
+      const v2dd c0a = w.c0a, c0b = w.c0b, c0c = w.c0c;
       v2dd ua[W + E + 1], ub[W + E + 1], da[W + E + 1], db[W + E + 1];   // [k]: row idx + k / idx - k (a = n_x, n_y; b = n_z, theta)
-      {
-        const uint32_t offR = hasR ? off0 + CELL : off0, offL = hasL ? off0 - CELL : off0;
-        ua[1] = ld(offR); ub[1] = ld(offR + 16);
-        da[1] = ld(offL); db[1] = ld(offL + 16);
 #pragma unroll
-        for (int k = 2; k <= W; ++k) {
-          uint32_t o = up_off(idx + k, flipped);
-          ua[k] = ld(o); ub[k] = ld(o + 16);
-          o = dn_off(idx - k, flipped);
-          da[k] = ld(o); db[k] = ld(o + 16);
-        }
+      for (int k = 1; k <= W; ++k) { ua[k] = w.ua[k]; ub[k] = w.ub[k]; da[k] = w.da[k]; db[k] = w.db[k]; }
 #pragma unroll
-        for (int k = W + 1; k <= W + E; ++k) { ua[k] = ub[k] = da[k] = db[k] = v2dd{0, 0}; }
-      }
+      for (int k = W + 1; k <= W + E; ++k) { ua[k] = ub[k] = da[k] = db[k] = v2dd{0, 0}; }
 
       PF_MARK(0);   // window requested and landed (behind the preceding commit's stores)
       // ---- the single-monomer part
@@ -339,10 +362,10 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
             const T3 Bu = nhat(xa, xb), Bl = nhat(ya, yb);
             capture(gu, Au, Bu, cu, nu);
             half_round(true, gu, Au, Bu, is_edge(xb.y), upper_p, upper);
-            Au = gu ? Bu : Au;
+            Au.x = gu ? Bu.x : Au.x; Au.y = gu ? Bu.y : Au.y; Au.z = gu ? Bu.z : Au.z;   // (component-wise: a select of two structs goes through memory)
             capture(gl, Al, Bl, cl, nl);
             half_round(false, gl, Al, Bl, is_edge(yb.y), lower_p, lower);
-            Al = gl ? Bl : Al;
+            Al.x = gl ? Bl.x : Al.x; Al.y = gl ? Bl.y : Al.y; Al.z = gl ? Bl.z : Al.z;
           }
         }
         upper_p = upper >= n - 1 ? (R)0 : upper_p;   // ran into the chain end: no link to test, :282-284
