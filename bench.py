@@ -36,8 +36,6 @@ import glob
 import hashlib
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -135,23 +133,13 @@ def parity_vs_cpu(ps, prec, n, chains, mc_steps, device, cpu_mean, cpu_se):
 def spawn_ranks(args) -> int:
     """--gpus N > 1 from a bare shell (WORLD_SIZE unset): start N fresh rank processes, one per GPU, BEFORE this
     process makes any GPU call (it never does: torch is not even imported here), relay rank 0's JSON line, and
-    fail if any rank fails.  The reference's analogue is `pmap` over worker processes
-    (run/interacting_dielectric_study.jl:37-47)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0]
-    rcs = [p.wait() for p in procs]
-    if any(rcs):
-        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
-        return 1
-    lines = [l for l in out0.decode().splitlines() if l.startswith("{")]
+    fail -- stopping the surviving ranks -- as soon as any rank fails (tools/rank_spawn.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from rank_spawn import spawn_ranks as spawn
+    rc, out0 = spawn(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+    if rc:
+        return rc
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
     if len(lines) != 1:
         print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
         return 1

@@ -57,7 +57,7 @@ constexpr uint32_t CELL = PSTAT_CLUSTER_GM_CELL;   // bytes per monomer
 #define PSTAT_GM_W 3
 #endif
 #ifndef PSTAT_GM_E
-#define PSTAT_GM_E 4
+#define PSTAT_GM_E 2
 #endif
 #ifndef PSTAT_GM_XREQ
 #define PSTAT_GM_XREQ 1
@@ -65,6 +65,10 @@ constexpr uint32_t CELL = PSTAT_CLUSTER_GM_CELL;   // bytes per monomer
 constexpr int W = PSTAT_GM_W;        // rows on either side of the moved monomer that every step requests up front
 constexpr int E = PSTAT_GM_E;        // further rows, requested after growth round XREQ by the ends still growing then
 constexpr int XREQ = PSTAT_GM_XREQ;
+#ifndef PSTAT_GM_D
+#define PSTAT_GM_D 2
+#endif
+constexpr int D = PSTAT_GM_D;        // rows in flight per end once a cluster has outgrown those
 static_assert(XREQ < W, "the outer rows are requested inside the window rounds");
 constexpr uint32_t OOB = 0x80000000u;  // past every working buffer (num_records < 2^31, checked by the host): no access
 
@@ -342,6 +346,16 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
           }
         }
         if (__builtin_amdgcn_ballot_w64(gu || gl) != 0) {
+          // (the ring of the rounds beyond W + E - 1, see below: rows W + E + 1 .. W + E + D, asked for by the ends that enter round W)
+          v2dd ra[D], rb[D], sa[D], sb[D];
+          int ring = W + E + 1;      // row offset of ring set 0's current row
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            uint32_t q = up_off(idx + ring + k, gu);
+            ra[k] = ld(q); rb[k] = ld(q + 16);
+            q = dn_off(idx - ring - k, gl);
+            sa[k] = ld(q); sb[k] = ld(q + 16);
+          }
           // ---- rounds W .. W + E - 1, out of the rows requested after round XREQ
 #pragma unroll
           for (int t = W; t < W + E; ++t) {
@@ -353,19 +367,26 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
             half_round(false, gl, Al, Bl, is_edge(db[t + 1].y), lower_p, lower);
             Al = Bl;
           }
-          // ---- beyond: one end in 2^(W + E) gets here; a row per round, waited for
+          // ---- beyond: one end in 2^(W + E) gets here -- rarely in a disordered chain, every step in an aligned one
+          // (cold or stiff: every link joins, clusters run to the chain ends).  A ring of D register sets, each row
+          // requested D rounds before its round; the ring was first filled when these ends entered round W.
           while (gu || gl) {
-            uint32_t q = up_off(upper + 1, gu);
-            const v2dd xa = ld(q), xb = ld(q + 16);
-            q = dn_off(lower - 1, gl);
-            const v2dd ya = ld(q), yb = ld(q + 16);
-            const T3 Bu = nhat(xa, xb), Bl = nhat(ya, yb);
-            capture(gu, Au, Bu, cu, nu);
-            half_round(true, gu, Au, Bu, is_edge(xb.y), upper_p, upper);
-            Au.x = gu ? Bu.x : Au.x; Au.y = gu ? Bu.y : Au.y; Au.z = gu ? Bu.z : Au.z;   // (component-wise: a select of two structs goes through memory)
-            capture(gl, Al, Bl, cl, nl);
-            half_round(false, gl, Al, Bl, is_edge(yb.y), lower_p, lower);
-            Al.x = gl ? Bl.x : Al.x; Al.y = gl ? Bl.y : Al.y; Al.z = gl ? Bl.z : Al.z;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+              const T3 Bu = nhat(ra[k], rb[k]), Bl = nhat(sa[k], sb[k]);
+              const bool eBu = is_edge(rb[k].y), eBl = is_edge(sb[k].y);
+              capture(gu, Au, Bu, cu, nu);
+              half_round(true, gu, Au, Bu, eBu, upper_p, upper);
+              Au = Bu;
+              capture(gl, Al, Bl, cl, nl);
+              half_round(false, gl, Al, Bl, eBl, lower_p, lower);
+              Al = Bl;
+              ring += 1;      // this set is free again: its next row is D rounds out
+              uint32_t q = up_off(idx + ring + D - 1, gu);
+              ra[k] = ld(q); rb[k] = ld(q + 16);
+              q = dn_off(idx - ring - D + 1, gl);
+              sa[k] = ld(q); sb[k] = ld(q + 16);
+            }
           }
         }
         upper_p = upper >= n - 1 ? (R)0 : upper_p;   // ran into the chain end: no link to test, :282-284
@@ -465,18 +486,18 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
               st((okf && k <= ku) ? off0 + (uint32_t)k * CELL + 16 : OOB, -ub[k].x, refl_theta(ub[k].y));
               st((okf && k <= kl) ? off0 - (uint32_t)k * CELL + 16 : OOB, -db[k].x, refl_theta(db[k].y));
             }
-            // members beyond the requested rows: read-modify-write, two rows of either side per pass
-            for (int i = W + E + 1; __builtin_amdgcn_ballot_w64(okf && (i <= ku || i <= kl)) != 0; i += 2) {
-              v2dd v[4];
+            // members beyond the requested rows: read-modify-write, four rows of either side per pass
+            for (int i = W + E + 1; __builtin_amdgcn_ballot_w64(okf && (i <= ku || i <= kl)) != 0; i += 4) {
+              v2dd v[8];
 #pragma unroll
-              for (int j = 0; j < 2; ++j) {
+              for (int j = 0; j < 4; ++j) {
                 v[j] = ld((okf && i + j <= ku) ? off0 + (uint32_t)(i + j) * CELL + 16 : OOB);
-                v[2 + j] = ld((okf && i + j <= kl) ? off0 - (uint32_t)(i + j) * CELL + 16 : OOB);
+                v[4 + j] = ld((okf && i + j <= kl) ? off0 - (uint32_t)(i + j) * CELL + 16 : OOB);
               }
 #pragma unroll
-              for (int j = 0; j < 2; ++j) {
+              for (int j = 0; j < 4; ++j) {
                 st((okf && i + j <= ku) ? off0 + (uint32_t)(i + j) * CELL + 16 : OOB, -v[j].x, refl_theta(v[j].y));
-                st((okf && i + j <= kl) ? off0 - (uint32_t)(i + j) * CELL + 16 : OOB, -v[2 + j].x, refl_theta(v[2 + j].y));
+                st((okf && i + j <= kl) ? off0 - (uint32_t)(i + j) * CELL + 16 : OOB, -v[4 + j].x, refl_theta(v[4 + j].y));
               }
             }
           }

@@ -77,3 +77,40 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
     bad = subprocess.run(cmd + ["--precision", "nonsense"], env=env, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and bad.stdout.strip() == ""
+
+
+def _scan(tmp_path, name, *extra, timeout=900):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = str(tmp_path / name)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "phase_scan.py"), "--points", "8", "--n", "48", "--steps", "1500",
+           "--burn-in", "400", "--burn-schedule", "10,1", "--out", out, *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    return r, out
+
+
+@pytest.mark.parametrize("main", ["clustering", "fixed-force"])
+def test_phase_scan_two_ranks_equal_one_rank_with_all_the_chains(tmp_path, main):
+    """BASELINE configs[4]'s workflow, multi-rank (the reference: pmap over grid points, run/K1_E0-kT-phase.jl:19-45):
+    `python tools/phase_scan.py --gpus 2 --backend gloo` from a bare shell starts two ranks (both on device 0 here),
+    each owning 64 of every grid point's 128 chains by global chain id, and merges with ONE all-reduce of the
+    [points x 41] reduction tensor; the CSV must equal the single-rank scan holding all 128 chains to 1e-11.  Annealed
+    ladder included (every rung a fresh mcmc() call in the clustering main).  A failing rank fails the command."""
+    common = ["--main", main, "--energy", "Ising", "--precision", "f64"]
+    two, out2 = _scan(tmp_path, "two.csv", "--gpus", "2", "--backend", "gloo", "--chains", "64", *common)
+    assert two.returncode == 0, two.stderr[-3000:]
+    assert "2 rank(s) [gloo]" in two.stderr
+    one, out1 = _scan(tmp_path, "one.csv", "--chains", "128", *common)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a = np.loadtxt(out1, delimiter=",", skiprows=1)
+    b = np.loadtxt(out2, delimiter=",", skiprows=1)
+    assert a.shape == b.shape == (8, 12) and np.all(a[:, 2] == 128) and np.all(b[:, 2] == 128)
+    np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-12)
+    assert np.all(np.isfinite(a)) and np.all((a[:, 11] > 0) & (a[:, 11] < 1))        # acceptance ratios
+    if main == "clustering":
+        bad, _ = _scan(tmp_path, "bad.csv", "--gpus", "2", "--backend", "gloo", "--chains", "64", "--precision", "nonsense")
+        assert bad.returncode != 0
+        # nccl with more ranks than GPUs: every rank beyond the device count exits, the launcher stops the rest
+        if __import__("polymer_stats_amd")._lib.load().pstat_device_count() == 1:
+            over, _ = _scan(tmp_path, "over.csv", "--gpus", "2", "--backend", "nccl", "--chains", "64", *common, timeout=300)
+            assert over.returncode != 0 and "only 1 GPU(s) visible" in over.stderr

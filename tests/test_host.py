@@ -205,3 +205,30 @@ def test_default_seed_is_fresh_entropy_and_echoed(capsys):
     pk = chost.default_pargs()
     q1 = chost.params_from_pargs(pk, 4, 0, 0)
     assert q1.seed == pk["seed"] and pk["seed"] is not None and pk["seed"] != s1
+
+
+def test_rank_launcher_stops_the_survivors_when_a_rank_fails(tmp_path):
+    """tools/rank_spawn.py (bench.py --gpus N, tools/phase_scan.py --gpus N): a rank that dies must not leave the others
+    waiting in a rendezvous -- they are terminated and the launcher returns non-zero promptly; on success rank 0's stdout
+    is relayed and the other ranks' stdout goes to stderr."""
+    import os
+    import subprocess
+    import sys
+    import time
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "r = int(os.environ['RANK']); mode = sys.argv[1]\n"
+        "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "if mode == 'fail' and r == 1: sys.exit(7)\n"
+        "if mode == 'fail': time.sleep(600)\n"
+        "print('hello from', r)\n")
+    drv = ("import sys; sys.path.insert(0, %r); from rank_spawn import spawn_ranks; rc, out = spawn_ranks(%r, [sys.argv[1]], 3); "
+           "sys.stdout.write(out); sys.exit(rc)") % (os.path.join(ROOT, "tools"), str(script))
+    ok = subprocess.run([sys.executable, "-c", drv, "ok"], capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0 and ok.stdout == "hello from 0\n" and "hello from 2" in ok.stderr
+    t0 = time.time()
+    bad = subprocess.run([sys.executable, "-c", drv, "fail"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and bad.stdout == "" and "rank 1 exited with code 7" in bad.stderr
+    assert time.time() - t0 < 30          # did not sit out the survivors' 600 s
