@@ -142,8 +142,18 @@ typedef struct pstat_summary {
   /* Failure surfacing.  The reference rejects a proposal whose energy is NaN silently
    * (inc/acceptance.jl:29-39: every comparison with NaN is false) and has no excluded volume, so with the
    * pair energies (inc/eap_chain.jl:200-207,215-228: 1/r^3) a chain can fall into r -> 0 and stay there.
-   *   nan_rejects       proposals, over all chains and recorded steps, whose trial energy was NaN or +-Inf
-   *                     (identically 0 for the non-interacting energy, whose dU is always finite);
+   *   nan_rejects       proposals, over all chains and recorded steps, whose trial energy AS THE DEVICE EVALUATES IT was
+   *                     NaN or +-Inf (identically 0 for the non-interacting energy, whose dU is always finite).  This is
+   *                     the device's arithmetic, not a replay of the reference's: whether a contact is r = 0 exactly
+   *                     (0 * inf = NaN) or r ~ 1e-17 (a finite 1e50) depends on the order positions are summed in.  The
+   *                     reference's cumsum (inc/eap_chain.jl:49-51) absorbs the 1e-16 components of a pole-clamped
+   *                     monomer into its running sum and lands two such monomers on exactly the same point; the kernels
+   *                     (bond vector b/2 (n_i + n_j) for neighbours, prefix scan / incremental shifts for all pairs) keep
+   *                     them 1e-17 apart.  Measured on one seeded case (23 monomers, --do-flips, 5 x 1500 steps): the
+   *                     CPU restatement of the reference's arithmetic counts 17, the device 0 -- and every one of those
+   *                     proposals is rejected on both sides anyway (the clamp gives sin(theta') = 0), which is why the
+   *                     trajectories agree bit for bit.  Where the non-finite value does not hinge on rounding (every
+   *                     pair at r = 0 with --mlen 0: tests/test_gpu_validation.py) the counts are equal.
    *   chains_collapsed  chains whose CURRENT energy has |U| > 1e3 * n * (kT + |E0| mu_max / 2 + b (|Fx| + |Fz|)),
    *                     mu_max = max(|K1|, |K2|) |E0| or |mu|: a thousand times what n separated monomers can hold
    *                     in field, force and thermal energy; only a 1/r^3 contact gets there (also counts NaN). */

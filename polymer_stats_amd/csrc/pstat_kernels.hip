@@ -179,7 +179,9 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   const R k2e = (R)(cc.K2 * cc.E0);
   const R mhalfE0 = (R)(-0.5 * cc.E0);
   const R hb = (R)(-cc.b / 2);
-  const R ising_scale = (R)(0.0795774715459476679 / fabs(cc.b * cc.b * cc.b / 8));   // f32 Ising: see the step
+  // f32 Ising: see the step.  (--mlen 0 puts every monomer on one point: the reference's pair term is 0 * inf = NaN there, not
+  // the +-inf that scaling a finite sum by 1 / 0 would give -- and -inf would be accepted.)
+  const R ising_scale = cc.b == 0.0 ? (R)__builtin_nan("") : (R)(0.0795774715459476679 / fabs(cc.b * cc.b * cc.b / 8));
   const R nbeta_log2e = (R)(-1.4426950408889634 / cc.kT);  // exp(-dU/kT) = exp2(dU * this)
   const double ninv_kT = -1.0 / cc.kT;
   (void)ninv_kT;

@@ -213,8 +213,9 @@ def test_f64_state_in_memory_matches_state_in_lds(ps, monkeypatch):
 
 def test_failure_counters(ps, oracle):
     """nan_rejects / chains_collapsed (ABI v5).  Non-interacting: identically zero.  A strongly coupled polar Ising
-    chain runs into r -> 0 between neighbours (the reference's behaviour): collapse is reported, and
-    the f64 kernel's count of non-finite trial energies equals the oracle's on the same streams."""
+    chain runs into r -> 0 between neighbours (the reference's behaviour): every chain is reported collapsed,
+    the reduction carries both counters and pstat_reset_averages clears the first.  (The counter's positive path:
+    test_nonfinite_energy_counter_counts_every_such_proposal below.)"""
     with ps.Ensemble(ps.default_params(num_chains=256, n=30, E0=1.0, Fz=1.0, seed=2)) as e:
         e.advance(3000)
         s = e.summary()
@@ -257,3 +258,56 @@ def test_a_timed_out_launch_poisons_the_handle(ps, monkeypatch):
     with ps.Ensemble(ps.default_params(num_chains=4096, precision=ps.F32, n=40, E0=1.0, Fz=0.5, seed=6)) as ok:
         ok.advance(7000)
         assert ok.summary().steps_per_chain == 7000
+
+
+@pytest.mark.parametrize("moves,et,prec", [
+    (0, 2, 1), (0, 2, 0), (0, 2, 2), (0, 1, 1), (0, 1, 0),            # fixed-force main: Ising (f64, f32, q16), all pairs
+    (1, 2, 1), (1, 2, 0), (1, 1, 1), (1, 1, 0), (1, 3, 1), (1, 3, 0),  # clustering main: Ising, interacting, cutoff
+])
+def test_nonfinite_energy_counter_counts_every_such_proposal(ps, oracle, monkeypatch, moves, et, prec):
+    """The positive path of pstat_summary.nan_rejects, where the non-finite value does not hinge on rounding: with
+    --mlen 0 every monomer sits on one point, every pair term of inc/eap_chain.jl:200-207 is 0 * inf = NaN in any
+    arithmetic, so EVERY proposal has a non-finite trial energy and is rejected (inc/acceptance.jl:29-39).  Every kernel
+    that evaluates a pair energy must count all of them -- equal to the oracle's count on the same chains -- leave the
+    angles where they were, carry the count in the reduction vector and through a checkpoint, and clear it with the
+    averagers.  The non-interacting energy never sees r: its count stays zero."""
+    nsteps, nchains, n = 700, 96, 43 if et == 2 else 21
+    kw = dict(n=n, E0=1.0, K1=0.8, K2=0.1, Fz=0.3, b=0.0, seed=5, energy_type=et, cutoff_radius=7.5)
+    if moves:
+        kw.update(cluster_prob=0.5, bend_mod=0.2)
+    homes = ("lds", "global") if (prec == 1 and et == 2) else ("default",)
+    for home in homes:
+        if home != "default":
+            monkeypatch.setenv("PSTAT_F64_STATE", home)
+        op, pp = both(nsteps, num_chains=nchains, precision=prec, **kw)
+        pp.move_set = moves
+        with ps.Ensemble(pp) as e:
+            first = e.chain_state(7)
+            e.advance(nsteps)
+            s = e.summary()
+            assert s.nan_rejects == nsteps * nchains, (home, s.nan_rejects)
+            assert s.acceptance_ratio == 0.0 and s.chains_collapsed == nchains
+            last = e.chain_state(7)
+            assert np.array_equal(first["theta"], last["theta"]) and np.array_equal(first["phi"], last["phi"])
+            red = e.reduce_host()
+            assert red[ps.NRED - 2] == nsteps * nchains and red[ps.NRED - 1] == nchains
+            if prec == 1:     # the oracle's count on the same chains (f64: same streams, same proposals)
+                for c in (0, 7, nchains - 1):
+                    o = oracle.run(op, chain_id=c, mode="cluster" if moves else "fast")
+                    assert o.nan_rejects == nsteps and o.nacc_total == 0
+            blob = e.checkpoint()
+            e.advance(100)
+            assert e.summary().nan_rejects == (nsteps + 100) * nchains
+            e.restore(blob)
+            assert e.summary().nan_rejects == nsteps * nchains
+            e.reset_averages()
+            assert e.summary().nan_rejects == 0
+            e.advance(50)
+            assert e.summary().nan_rejects == 50 * nchains
+    # the non-interacting energy under the same --mlen 0: never a non-finite proposal
+    op, pp = both(nsteps, num_chains=nchains, precision=prec, **dict(kw, energy_type=0))
+    pp.move_set = moves
+    with ps.Ensemble(pp) as e:
+        e.advance(nsteps)
+        s = e.summary()
+        assert s.nan_rejects == 0 and s.chains_collapsed == 0 and s.acceptance_ratio > 0.1
