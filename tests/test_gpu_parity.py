@@ -588,3 +588,102 @@ def test_f32_running_totals_do_not_drift(ps, moves):
             m = e.microstate(c)
             worst = max(worst, np.abs(m[:3] - r).max(), np.abs(m[3:6] - p).max(), abs(m[6] - U))
         assert worst < 1.2e-3, worst
+
+
+@pytest.mark.parametrize("Fz", [0.0, 1.0, 5.0])
+def test_f64_bit_parity_headline_instantiation(ps, oracle, Fz):
+    """BASELINE configs[1] on the exact instantiation bench.py times -- sweep_kernel<double, Mwc64x, dielectric,
+    non-interacting, no Fx, no rare options, cells in memory> at n = 100 -- directly against the oracle (not through the
+    LDS variant): three points of the Fz sweep of run/noninteracting-compare-with-clustering_2021-09-24.jl:21, 70 chains
+    (one full wave and one 6-lane wave), adaptation active.  Reference lines: mcmc_eap_chain.jl:276-328."""
+    op, pp = both(6000, num_chains=70, precision=ps.F64, n=100, E0=1.0, K1=1.0, K2=0.0, Fz=Fz, kT=1.0, seed=20260501)
+    with ps.Ensemble(pp) as e:
+        assert "state in L2" in e.launch_info().kernel.decode()
+        e.advance(2500); e.advance(3500)
+        e.sync()
+        for c in range(70):
+            o = oracle.run(op, chain_id=c, mode="fast", trace=True)
+            g = e.chain_state(c)
+            assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (Fz, c)
+            assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total
+            assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step
+            np.testing.assert_allclose(g["sums"], o.sums, rtol=1e-9, atol=1e-7)
+            np.testing.assert_allclose(e.microstate(c), np.r_[o.r, o.p, o.U], rtol=1e-9, atol=1e-9)
+        assert e.summary().nan_rejects == 0
+
+
+def test_f64_bit_parity_phase_grid_point_n200(ps, oracle):
+    """BASELINE configs[4] at the default precision against the oracle: grid points of run/K1_E0-kT-phase.jl:21-24 (n = 200,
+    K1 = 1, K2 = 0, b = 1, F = 0, Ising energy) batched in one handle like tools/phase_scan.py does; warm enough that
+    no chain collapses in 1500 steps.  Cells in memory, three rows fetched per step (run_segment, ST = 2, Ising)."""
+    grid = [(0.2, 10.0 ** 0.6), (1.0, 10.0 ** 1.0), (0.4, 10.0 ** 2.0)]
+    cases = [ps.default_params(n=200, E0=E0, kT=kT, K1=1.0, K2=0.0, b=1.0, num_chains=66, seed=20260501 + k, precision=ps.F64,
+                               energy_type=ps.ISING) for k, (E0, kT) in enumerate(grid)]
+    with ps.Ensemble(cases) as e:
+        assert "state in L2" in e.launch_info().kernel.decode()
+        e.advance(1500)
+        e.sync()
+        for k, (E0, kT) in enumerate(grid):
+            op, _ = both(1500, num_chains=66, precision=ps.F64, n=200, E0=E0, kT=kT, K1=1.0, K2=0.0, b=1.0, seed=20260501 + k,
+                         energy_type=ps.ISING)
+            for c in (0, 63, 64, 65):
+                o = oracle.run(op, chain_id=c, mode="fast", trace=True)
+                g = e.chain_state(k * 66 + c)
+                assert abs(o.U) < 1e3 * 200 * kT, "collapsed: not a trajectory-parity case"
+                assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (k, c)
+                assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total
+                np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-7, atol=1e-7)
+
+
+def test_f64_sweep_fuzz_over_both_state_homes(ps, oracle, monkeypatch):
+    """A seeded 150-configuration slice of tests/fuzz_f64.py (the 3 000-case run of round 2 was a builder-run script):
+    non-interacting and Ising energies, every option, both generators, chain lengths 1 ... 140, the cells forced into LDS
+    or into memory (ST = 2: the two-step-deep pipeline and its forwarding, hit hardest by SHORT chains) with 0 / 1 / 5 /
+    39 rows kept in LDS, a launch split and a re-init in every run: the oracle's trajectory bit for bit."""
+    rng = np.random.default_rng(20260503)
+    homes = {"lds": 0, "global": 0, "auto": 0}
+    for trial in range(150):
+        et = int(rng.choice([0, 0, 2]))
+        where = str(rng.choice(["lds", "global", "global", "auto"]))
+        n = int(rng.integers(1, 12)) if rng.random() < 0.4 else int(rng.integers(12, 141))
+        kw = dict(n=n, E0=float(rng.uniform(0, 2)), K1=float(rng.uniform(0, 1.2)), K2=float(rng.uniform(0, 0.5)),
+                  mu=float(rng.uniform(0.01, 0.6)), kT=float(10 ** rng.uniform(-0.5, 0.7)), Fz=float(rng.uniform(-1, 2)),
+                  Fx=float(rng.choice([0.0, rng.uniform(-1, 1)])), b=float(rng.uniform(0.5, 2.0)),
+                  chain_type=int(rng.integers(0, 2)), energy_type=et, do_flips=int(rng.integers(0, 2)),
+                  umbrella=int(rng.integers(0, 2)), steps_per_adjust=int(rng.choice([50, 137, 400, 2500])),
+                  adj_scale=float(rng.choice([1.0, 1.1, 1.3])), rng=int(rng.integers(0, 2)), seed=int(rng.integers(0, 2 ** 40)))
+        if et == 2:      # keep the Ising coupling weak: collapsed chains amplify rounding into decisions
+            kw.update(K1=kw["K1"] * 0.3, K2=kw["K2"] * 0.2, mu=kw["mu"] * 0.3)
+        nsteps = int(rng.choice([700, 1500, 3001]))
+        inits = int(rng.choice([1, 1, 2]))
+        force = int(rng.integers(0, 2))
+        cid = int(rng.integers(0, 2 ** 33))
+        if kw["rng"] == 0:
+            cid %= (1 << 22) - 140
+        nch = int(rng.choice([3, 65, 130]))
+        if where == "auto":
+            monkeypatch.delenv("PSTAT_F64_STATE", raising=False)
+        else:
+            monkeypatch.setenv("PSTAT_F64_STATE", where)
+        rows = int(rng.choice([0, 1, 5, 39]))
+        monkeypatch.setenv("PSTAT_F64_LDS_ROWS", str(rows))
+        op, pp = both(nsteps, num_chains=nch, precision=ps.F64, num_inits=inits, force_init=force, chain_id0=cid, **kw)
+        with ps.Ensemble(pp) as e:
+            in_memory = "state in L2" in e.launch_info().kernel.decode()
+            assert in_memory == (where == "global" or (where == "auto" and n > 40))
+            homes[where] += 1
+            for k in range(inits):
+                half = nsteps // 3
+                e.advance(half); e.advance(nsteps - half)          # a launch split in every run
+                if k + 1 < inits:
+                    e.reinit(bool(force))
+            e.sync()
+            for c in sorted(set([0, nch - 1, nch // 2])):
+                o = oracle.run(op, chain_id=pp.chain_id0 + c, mode="fast", trace=True)
+                g = e.chain_state(c)
+                ctx = (trial, where, rows, nch, cid, nsteps, inits, force, kw)
+                assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), ctx
+                assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total, ctx
+                assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step, ctx
+                np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-7, atol=1e-7, err_msg=str(ctx))
+    assert min(homes.values()) > 20, homes
