@@ -349,8 +349,10 @@ __device__ __forceinline__ float acos_r(float x) {
 // asin(t) = t + t z g(z), z = t^2 <= 1/4 and g a degree-12 polynomial (Chebyshev-node fit of (asin(sqrt z)/sqrt z - 1)/z
 // on [0, 1/4], relative truncation error 3.6e-18):  |x| < 1/2: acos x = pi/2 - asin x;  |x| >= 1/2: with z = (1 - |x|)/2,
 // acos |x| = 2 asin(sqrt z), mirrored for x < 0.  sqrt z by v_rsq_f64 + one Goldschmidt step.  Max error 1.2 ulp
-// (tools/mathcheck); acos(1) = 0 and acos(-1) = fl(pi) exactly.  Bond angles feed the bending energy and the <psi>
-// averager only -- nothing that decides which angles a chain visits.
+// (tools/mathcheck); acos(1) = 0 and acos(-1) = fl(pi) exactly.  Bond angles feed the <psi> averager and, with
+// --bend-mod, the bending energy kappa/2 (psi - psi0)^2, hence dU and the Metropolis decision of the clustering main:
+// against the oracle's libm acos that perturbs dU by ~1 ulp of psi, the same 1e-16 class as the hot-loop sincos (a
+// decision compares against a 23-bit uniform: it moves with probability ~1e-16).
 __device__ __forceinline__ double acos_r(double x) {
   const double a = fabs(x);
   const bool big = a >= 0.5;
