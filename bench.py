@@ -46,7 +46,8 @@ FZ_SWEEP = [round(0.05 * i, 2) for i in range(21)] + [1.5 + 0.5 * i for i in ran
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz = 7.86e13 f32 lane-ops/s (f64: half of it)
 LDS_PEAK_GBS = 256 * 256 * 2.4              # CUs x 256 B/clk (MI355X_MICROARCH.md, LDS) x GHz = 157 TB/s
-VALU_OPS_ESTIMATE = {"f32": 85, "f64": 280, "q16": 85}   # last PMC counts (profiles/r02); replaced by the stamped record when valid
+VALU_OPS_ESTIMATE = {"f32": 85, "f64": 257, "q16": 85}   # last PMC counts (profiles/r02); replaced by the stamped record when valid
+VALU_F64_OPS_ESTIMATE = {"f64": 128.0}                   # of which f64 ops; likewise replaced
 STATE_BYTES = {"f32": 16, "f64": 32, "q16": 8}              # one state cell read + written per attempted update
 DTYPE = {"f32": "f32 state+transcendentals, f64 running sums", "f64": "f64",
          "q16": "u16 lattice angles, f32 transcendentals, f64 running sums"}
@@ -160,6 +161,7 @@ def main():
     ap.add_argument("--no-fast-path", action="store_true", help="skip the sibling f32 measurement")
     ap.add_argument("--rng", choices=["mwc64x", "xoshiro128++"], default="mwc64x",
                     help="per-chain generator (default MWC64X; xoshiro128++ is the north star's named one, measured slower here)")
+    ap.add_argument("--no-rng-named", action="store_true", help="skip the sibling f64 measurement under xoshiro128++")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -215,9 +217,10 @@ def main():
     nstep_total = args.steps + args.warmup
     red = torch.zeros(ps.NRED, dtype=torch.float64, device="cuda")
 
-    def measure(precision: str):
+    def measure(precision: str, rng_name: str = None):
         """W warm-up + K timed bench steps of the sweep kernel in `precision`; returns the timing record."""
         prec = PREC[precision]
+        rng_name = rng_name or args.rng
         with torch.cuda.stream(stream):
             # one ensemble per bench step (a point of the Fz sweep), initialised on the device up front
             ens = []
@@ -225,7 +228,7 @@ def main():
                 p = ps.default_params(n=args.n, E0=1.0, K1=1.0, K2=0.0, kT=1.0, b=1.0, Fz=FZ_SWEEP[i % len(FZ_SWEEP)],
                                       num_chains=args.chains, chain_id0=rank * args.chains,
                                       seed=20260501 + i, precision=prec, device=local_rank,
-                                      rng=ps.RNG_XOSHIRO128PP if args.rng == "xoshiro128++" else ps.RNG_MWC64X)
+                                      rng=ps.RNG_XOSHIRO128PP if rng_name == "xoshiro128++" else ps.RNG_MWC64X)
                 ens.append(ps.Ensemble(p, stream=stream.cuda_stream))
             info = ens[0].launch_info()
             log(f"rank {rank}: {precision}: {nstep_total} ensembles ready; kernel {info.kernel.decode()} "
@@ -280,14 +283,21 @@ def main():
         rate = upd_per_launch / (mean_ms * 1e-3)             # updates/s of the kernel alone
         achieved = STATE_BYTES[precision] * rate / 1e9
         key = f"{precision}_n{args.n}_c{args.chains}_s{args.mc_steps}"
-        traffic, valu_ops, src = None, VALU_OPS_ESTIMATE[precision], "estimate (no PMC record for these kernel sources)"
+        traffic, traffic_raw, traffic_how = None, None, None
+        valu_ops, src = VALU_OPS_ESTIMATE[precision], "estimate (no PMC record for these kernel sources)"
+        f64_ops = VALU_F64_OPS_ESTIMATE.get(precision, 0.0)
         if pmc and key in pmc.get("records", {}):
             r = pmc["records"][key]
-            traffic = r.get("hbm_bytes_per_launch")
+            traffic, traffic_raw, traffic_how = r.get("hbm_bytes_per_launch"), r.get("raw_bytes_per_launch"), r.get("traffic_method")
             if r.get("valu_instructions_per_update_per_lane"):
                 valu_ops = r["valu_instructions_per_update_per_lane"]
                 src = "SQ_INSTS_VALU x 64 / updates, profiles/pmc_traffic.json (stamp = sha256 of the kernel sources)"
-        valu_peak = VALU_LANE_OPS_PEAK * (0.5 if precision == "f64" else 1.0)   # v_fma_f64: 16 lanes/clk/SIMD
+            if r.get("valu_f64_instructions_per_update_per_lane") is not None:
+                f64_ops = r["valu_f64_instructions_per_update_per_lane"]
+        # an f64 op (v_fma/add/mul_f64 and the f64 transcendentals) issues at 16 lanes per clock and SIMD, everything else
+        # (integer, select, f32, conversions: the generator, the address steering, the f32 Metropolis filter) at 32
+        other_ops = max(0.0, valu_ops - f64_ops)
+        issue_frac = rate * (f64_ops / (0.5 * VALU_LANE_OPS_PEAK) + other_ops / VALU_LANE_OPS_PEAK)
         last, info = rec["last"], rec["info"]
         in_memory = "state in L2" in info.kernel.decode()
         # state in memory: (LDS bytes / 1 KiB per row of 64 lanes x 16 B) - 1 trash row = monomers whose cells are in LDS
@@ -298,17 +308,24 @@ def main():
             "dtype": DTYPE[precision],
             "kernel": info.kernel.decode(), "lds_bytes_per_wg": info.lds_bytes, "lanes_per_wg": info.lanes_per_block,
             "workgroups": int(info.blocks), "wg_per_cu_resident": info.blocks_per_cu,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": mean_ms,
-                         "equivalent": not in_memory,
+            "roofline": {"bound": "hbm", "bound_measured": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw,
+                         "traffic_note": ("`traffic` = fabric bytes per launch (L2 misses + write-backs; for this 105 MB working set they "
+                                          "are served by the Infinity Cache, not HBM): " + (traffic_how or "no PMC record for these kernel sources") +
+                                          "; `traffic_raw` = (FETCH_SIZE + WRITE_SIZE)*1024 as rocprofv3 prints them.  FETCH_SIZE tallies every "
+                                          "128-byte fabric request at 64 bytes, for scattered 16-byte reads as for streaming ones "
+                                          "(profiles/r03/fetch_calib.txt: 1.07e9 scattered 16-byte reads = 1.07e9 requests, all 128-byte)"),
+                         "kernel_ms": mean_ms, "equivalent": not in_memory,
                          "note": ("algorithmic bytes = %d B/update x %d updates per launch / HIP-event kernel time; " % (STATE_BYTES[precision], upd_per_launch)) +
                                  ("part of the state lives in memory (L2 / Infinity Cache): `traffic` is what the fabric carried; "
                                   "the kernel's bound is `valu`" if in_memory else
                                   "state is on-chip resident, so this is an equivalent rate, not HBM traffic (see `traffic`); "
                                   "the kernel's real bound is `valu`")},
-            "valu": {"bound": "valu-issue", "achieved": rate * valu_ops / 1e12, "peak": valu_peak / 1e12,
-                     "unit": "T lane-ops/s", "frac": rate * valu_ops / valu_peak,
-                     "ops_per_update": valu_ops, "ops_source": src},
+            "valu": {"bound": "valu-issue", "achieved": rate * valu_ops / 1e12, "peak": VALU_LANE_OPS_PEAK / 1e12,
+                     "unit": "T lane-ops/s", "frac": issue_frac,
+                     "ops_per_update": valu_ops, "f64_ops_per_update": f64_ops, "other_ops_per_update": other_ops,
+                     "frac_note": "issue time: f64 ops priced at 16 lanes/clk/SIMD (3.93e13 lane-ops/s), all others at 32 (7.86e13)",
+                     "ops_source": src},
             "lds": {"bound": "lds-bandwidth", "achieved": lds_share * STATE_BYTES[precision] * rate / 1e9, "peak": LDS_PEAK_GBS,
                     "unit": "GB/s", "frac": lds_share * STATE_BYTES[precision] * rate / 1e9 / LDS_PEAK_GBS,
                     "note": "one state cell read + one written per update (ds_read/ds_write of %d B)%s" %
@@ -320,9 +337,11 @@ def main():
         }
 
     head = measure(args.precision)
-    fast = None
+    fast = named = None
     if args.precision == "f64" and not args.no_fast_path:
         fast = measure("f32")
+    if args.precision == "f64" and args.rng == "mwc64x" and not args.no_rng_named:
+        named = measure("f64", "xoshiro128++")    # the generator the north star names, on the headline kernel
 
     if rank == 0:
         pmc = None
@@ -356,8 +375,16 @@ def main():
             f = price(fast, pmc)
             out["fast_path"] = {k: f[k] for k in ("value", "ms_per_step", "dtype", "kernel", "lanes_per_wg",
                                                   "wg_per_cu_resident", "roofline", "valu", "lds", "check")}
-            out["fast_path"]["bias_bound"] = ("<= 5e-6 relative on every pooled average against the closed form "
-                                              "(profiles/r01_final/bias_f32_long.json; DESIGN.md section 5)")
+            out["fast_path"]["bias_bound"] = ("<= 5e-6 relative on every pooled average against the closed form (round-1 evidence: "
+                                              "profiles/r01_final/bias_f32_long.json, 6.6e12 updates; the f32 kernel is unchanged "
+                                              "since; DESIGN.md section 5)")
+        if named is not None:
+            g = price(named, None)
+            out["rng_named"] = {"rng": "xoshiro128++ (Philox4x32-10-seeded per chain; BASELINE.json north_star: 'Philox/xoshiro counter-based RNG')",
+                                "value": g["value"], "ms_per_step": g["ms_per_step"], "dtype": g["dtype"], "kernel": g["kernel"],
+                                "roofline_frac": g["roofline"]["frac"], "kernel_ms": g["roofline"]["kernel_ms"], "check": g["check"],
+                                "note": "same kernel, workload, K and W as the headline, which runs the default MWC64X "
+                                        "(one v_mad_u64_u32 + one v_xor per draw against ten 32-bit ops; DESIGN.md section 4)"}
         if world == 1 and not args.no_cpu_baseline:
             base, cpu_mean, cpu_se = cpu_baseline(args.n, args.mc_steps)
             base["parity"] = parity_vs_cpu(ps, PREC[args.precision], args.n, args.chains, args.mc_steps, local_rank, cpu_mean, cpu_se)

@@ -27,6 +27,10 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.dst, exist_ok=True)
     cmd = open(os.path.join(a.src, "command.txt")).read().strip()
+    import bench
+    stamp = bench.kernel_source_hash()      # every summary names the kernel sources it was taken on
+    stamp_line = (f"# kernel_source_sha256_16: {stamp}   (sha256 over polymer_stats_amd/csrc/*.hip, *.h, Makefile and "
+                  f"include/pstat.h at collection time; bench.kernel_source_hash())\n")
 
     # kernel trace: per-dispatch durations of the kernel, warm-up launch dropped
     tr = glob.glob(os.path.join(a.src, "trace", "**", "*kernel_trace.csv"), recursive=True)[0]
@@ -36,6 +40,7 @@ def main():
     full = [d for d in dur[1:] if d > 0.5 * max(dur[1:])]
     kname = rows[0]["Kernel_Name"]
     with open(os.path.join(a.dst, a.name + "_kernel_trace.csv"), "w") as f:
+        f.write(stamp_line)
         f.write(f"# rocprofv3 --kernel-trace --stats -- python3 {cmd}\n")
         f.write("# per-dispatch durations of the kernel; the first dispatch (warm-up) is excluded from the summary row\n")
         f.write("kernel,dispatches_total,dispatches_summarised,avg_ms,min_ms,max_ms,first_dispatch_ms\n")
@@ -59,7 +64,7 @@ def main():
             kinfo = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "VGPR_Count", "Accum_VGPR_Count",
                                         "SGPR_Count", "LDS_Block_Size") if k in r}
     mean = {}
-    lines = [f"# rocprofv3 --pmc <group> --kernel-trace -- python3 {cmd}   (one counter group per run)",
+    lines = [stamp_line.rstrip(), f"# rocprofv3 --pmc <group> --kernel-trace -- python3 {cmd}   (one counter group per run)",
              "# kernel: " + json.dumps(kinfo),
              "# rows: mean over the kernel's dispatches EXCEPT its first one (the warm-up launch)",
              "counter,dispatches,mean_per_dispatch,min,max"]
@@ -71,18 +76,34 @@ def main():
         lines.append(f"{name},{len(v)},{mean[name]:.6g},{min(v):.6g},{max(v):.6g}")
     if a.updates and "SQ_INSTS_VALU" in mean:
         lines.append(f"# VALU wave-instructions per update per lane (x64 lanes / updates): {mean['SQ_INSTS_VALU'] * 64 / a.updates:.4f}")
+    raw = corrected = exact = None
     if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
-        hbm = (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024
-        lines.append(f"# HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reads half: "
-                     f"MI355X_MICROARCH.md, HBM): {hbm:.6g}")
+        raw = (mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024
+        corrected = (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024
+        lines.append(f"# fabric bytes per launch, raw = (FETCH_SIZE + WRITE_SIZE)*1024: {raw:.6g}")
+        lines.append(f"# fabric bytes per launch, guide's correction for wide streaming reads = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                     f"(MI355X_MICROARCH.md, HBM: FETCH_SIZE tallies a 128-byte request at 64): {corrected:.6g}")
+    if all(k in mean for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")):
+        n32, n64, n128, nall = (mean[k] for k in ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum",
+                                                  "TCC_EA0_RDREQ_sum"))
+        rd = 32 * n32 + 64 * n64 + 128 * n128
+        lines.append(f"# fabric READ bytes per launch by request size = 32*{n32:.6g} + 64*{n64:.6g} + 128*{n128:.6g} = {rd:.6g} "
+                     f"({100 * n128 / max(nall, 1):.1f} % of the {nall:.6g} requests are 128-byte ones"
+                     + (f"; FETCH_SIZE*1024 = {mean['FETCH_SIZE'] * 1024:.6g} is {mean['FETCH_SIZE'] * 1024 / rd:.3f} of it)" if "FETCH_SIZE" in mean else ")"))
+        if "WRITE_SIZE" in mean:
+            exact = rd + mean["WRITE_SIZE"] * 1024
+            lines.append(f"# fabric bytes per launch, exact reads + WRITE_SIZE*1024: {exact:.6g}")
+    f64n = [mean.get(k) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64")]
+    f64_insts = sum(f64n) if all(v is not None for v in f64n) else None
+    if f64_insts is not None and "SQ_INSTS_VALU" in mean:
+        lines.append(f"# f64 VALU wave-instructions (FMA + ADD + MUL + TRANS): {f64_insts:.6g} = "
+                     f"{100 * f64_insts / mean['SQ_INSTS_VALU']:.1f} % of SQ_INSTS_VALU")
     open(os.path.join(a.dst, a.name + "_pmc.csv"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
     print("kernel avg ms (warm-up excluded):", kern_ms, "over", len(full), "dispatches; first:", dur[0])
 
     if a.record:
-        import bench
         path = os.path.join(os.path.dirname(a.dst.rstrip("/")), "pmc_traffic.json")
-        stamp = bench.kernel_source_hash()
         try:
             rec = json.load(open(path))
             if rec.get("kernel_source_sha256_16") != stamp:
@@ -94,12 +115,18 @@ def main():
         rec["note"] = ("collected by tools/collect_pmc.sh + tools/summarize_pmc.py; bench.py uses a record only while the "
                        "sha256 of polymer_stats_amd/csrc/* + include/pstat.h still equals the stamp")
         rec["records"][a.record] = {
-            "hbm_bytes_per_launch": (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024,
-            "fetch_size_kib": mean["FETCH_SIZE"], "write_size_kib": mean["WRITE_SIZE"],
-            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reads half, MI355X_MICROARCH.md HBM)",
+            # `hbm_bytes_per_launch` = the figure bench.py prints as roofline.traffic: exact where the request-size
+            # counters were collected, else the guide's streaming-read correction
+            "hbm_bytes_per_launch": exact if exact is not None else corrected,
+            "traffic_method": ("32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B + WRITE_SIZE*1024 (TCC_EA0 request-size counters)"
+                               if exact is not None else
+                               "(2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md HBM: wide streaming reads; uncalibrated for scattered 16-byte reads)"),
+            "raw_bytes_per_launch": raw, "streaming_corrected_bytes_per_launch": corrected,
+            "fetch_size_kib": mean.get("FETCH_SIZE"), "write_size_kib": mean.get("WRITE_SIZE"),
             "round": os.path.basename(a.dst.rstrip("/")),
             "valu_wave_instructions_per_launch": mean["SQ_INSTS_VALU"],
             "valu_instructions_per_update_per_lane": mean["SQ_INSTS_VALU"] * 64 / a.updates,
+            "valu_f64_instructions_per_update_per_lane": (f64_insts * 64 / a.updates) if f64_insts is not None else None,
             "kernel_ms_rocprof_trace": kern_ms,
         }
         json.dump(rec, open(path, "w"), indent=1)
