@@ -115,14 +115,18 @@ __device__ __forceinline__ R ring_pair_sum(R4 *ringA, R2 *ringB_, const int lane
         // f64: a double4 entry would be read as two ds_read_b128 at a 32-byte lane stride -- two-way bank conflicts on
         // every read (measured: 38 % of the LDS-active cycles of the f64 interacting kernel).  (x, y) and (z, mu_x)
         // therefore live in two separate arrays of 16-byte entries, like (mu_y, mu_z).
+        // With M >= 2 monomers per lane the entries are laid out MONOMER-MAJOR, [j][slot]: consecutive lanes then read
+        // consecutive 16-byte entries (lane-major, a lane stride of 16 M bytes, gave two-way conflicts at M = 2 -- measured on
+        // the clustering main's all-pairs kernel at n = 100: SQ_LDS_BANK_CONFLICT 37 % of SQ_LDS_IDX_ACTIVE).
         R2 *rxy = reinterpret_cast<R2 *>(ringA), *rzm = rxy + 128 * M;
         const R2 xy = {va[j].x, va[j].y}, zm = {va[j].z, va[j].w};
-        rxy[lane * M + j] = xy; rxy[(lane + L) * M + j] = xy;
-        rzm[lane * M + j] = zm; rzm[(lane + L) * M + j] = zm;
+        rxy[j * 128 + lane] = xy; rxy[j * 128 + lane + L] = xy;
+        rzm[j * 128 + lane] = zm; rzm[j * 128 + lane + L] = zm;
+        ringB[j * 128 + lane] = vb[j]; ringB[j * 128 + lane + L] = vb[j];
       } else {
         ringA[lane * M + j] = va[j]; ringA[(lane + L) * M + j] = va[j];
+        ringB[lane * M + j] = vb[j]; ringB[(lane + L) * M + j] = vb[j];
       }
-      ringB[lane * M + j] = vb[j]; ringB[(lane + L) * M + j] = vb[j];
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -167,14 +171,16 @@ __device__ __forceinline__ R ring_pair_sum(R4 *ringA, R2 *ringB_, const int lane
 #pragma unroll
     for (int jp = 0; jp < M; ++jp) {
       R4 qa;
+      RB qb;
       if constexpr (sizeof(R) == 8) {
-        const R2 *rxy = reinterpret_cast<const R2 *>(ringA) + me * M, *rzm = rxy + 128 * M;
-        const R2 xy = rxy[(L - k) * M + jp], zm = rzm[(L - k) * M + jp];
+        const R2 *rxy = reinterpret_cast<const R2 *>(ringA) + me, *rzm = rxy + 128 * M;
+        const R2 xy = rxy[jp * 128 + (L - k)], zm = rzm[jp * 128 + (L - k)];
         qa.x = xy.x; qa.y = xy.y; qa.z = zm.x; qa.w = zm.y;
+        qb = (ringB + me)[jp * 128 + (L - k)];
       } else {
         qa = pa[(L - k) * M + jp];
+        qb = pb[(L - k) * M + jp];
       }
-      const RB qb = pb[(L - k) * M + jp];
 #pragma unroll
       for (int j = 0; j < M; ++j) accum(t, j, qa, qb);
     }
