@@ -1021,12 +1021,15 @@ SweepFn pick_sweep_f64g(const LaunchCfg &cfg);
 // f64 cells are 16 bytes: LDS seats 160 KiB / (16 n) chains per CU.  Once that is fewer than four full waves
 // (n > 40) the non-interacting f64 sweep keeps its cells in global memory instead and runs 64 lanes on every
 // SIMD (run_segment, ST = 2).  PSTAT_F64_STATE=lds|global overrides the choice (experiments, tests).
-// The clustering main's chain-per-lane kernel follows the same rule (pstat_cluster_gm.hip).
+// The clustering main's chain-per-lane kernel always keeps its chains in memory (pstat_cluster_gm.hip).
 bool f64_state_global(const LaunchCfg &cfg, int64_t n) {
   if (cfg.precision != PSTAT_F64 || (cfg.energy_type != PSTAT_NONINTERACTING && cfg.energy_type != PSTAT_ISING)) return false;
   const char *e = getenv("PSTAT_F64_STATE");
   if (e && e[0] == 'l') return false;
   if (e && e[0] == 'g') return true;
+  // the clustering main's kernel in memory carries the trigonometric cache and is faster at every chain length
+  // (measured n = 10 / 20 / 40: 1.5e10 / 1.4e10 / 1.3e10 proposals/s against 1.0e10 with the cells in LDS)
+  if (cfg.move_set == PSTAT_MOVES_CLUSTER) return true;
   return n * 16 * 256 > 160 * 1024;
 }
 

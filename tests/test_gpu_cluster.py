@@ -29,8 +29,8 @@ def ps():
 @pytest.fixture(params=["lds", "memory"])
 def f64_home(request, monkeypatch):
     """Where the f64 chain-per-lane cluster kernel keeps a chain while a segment runs: (theta, phi) cells in LDS
-    (pstat_cluster.hip) or 48-byte cells with the reference's trigonometric cache in device memory
-    (pstat_cluster_gm.hip; the default for n > 40).  Every f64 parity test below runs on both."""
+    (pstat_cluster.hip) or 40-byte cells with the reference's trigonometric cache in device memory
+    (pstat_cluster_gm.hip; the default).  Every f64 parity test below runs on both."""
     monkeypatch.setenv("PSTAT_F64_STATE", "global" if request.param == "memory" else "lds")
     return request.param
 
@@ -385,8 +385,8 @@ def test_f64_bit_parity_random_cluster_configurations(ps, oracle, f64_home):
     (41, dict(E0=1.0, mu=0.2, chain_type=1, Fz=0.4, Fx=0.3, energy_type=2, umbrella=1, rng=1)),
 ])
 def test_f64_cluster_long_chains_bit_parity_in_the_default_home(ps, oracle, n, kw):
-    """The chain lengths the reference's sweeps launch this main with (n = 100, 200) run with the chains in device
-    memory by default (n > 40): trajectories against the oracle's literal clustering main, 70 chains = one full and one
+    """The chain lengths the reference's sweeps launch this main with (n = 100, 200) on the default home (device
+    memory): trajectories against the oracle's literal clustering main, 70 chains = one full and one
     6-lane wave, a launch split included (weak coupling: no 1/r^3 collapse in 1200 steps)."""
     nsteps = 1200
     op, pp = _pair(ps, nsteps, 70, ps.F64, n=n, seed=71, cluster_prob=0.5, steps_per_adjust=400, **kw)
@@ -437,6 +437,6 @@ def test_f64_cluster_state_in_memory_matches_state_in_lds(ps, monkeypatch):
             np.testing.assert_allclose(x["normalizer"], y["normalizer"], rtol=1e-12)
         np.testing.assert_allclose(res["lds"][-1], res["global"][-1], rtol=1e-10, atol=1e-8)
     monkeypatch.delenv("PSTAT_F64_STATE")
-    for n, mem in ((40, False), (41, True)):     # LDS seats four full waves per CU up to n = 40
+    for n in (2, 40, 41):     # the default home is device memory at every chain length (the cache of n-hat pays everywhere)
         with ps.Ensemble(ps.default_params(num_chains=64, precision=ps.F64, n=n, move_set=ps.MOVES_CLUSTER)) as e:
-            assert ("state in memory" in e.launch_info().kernel.decode()) == mem
+            assert "state in memory" in e.launch_info().kernel.decode()
