@@ -1,0 +1,23 @@
+#!/bin/bash
+# Every rocprofv3 record of a round, on the kernel sources as they stand (run on the GPU box):
+#   bash tools/collect_round_profiles.sh r03      -> gpurun_out/prof_<tag>_*/ (raw), then
+#   bash tools/summarize_round_profiles.sh r03    -> profiles/<tag>/*.csv + profiles/pmc_traffic.json (run anywhere)
+# One kernel trace + separate --pmc passes per workload (tools/collect_pmc.sh); every summary is stamped with the sha256
+# of the kernel sources (tools/summarize_pmc.py), so a profile can always be attributed to the code it describes.
+set -uo pipefail
+tag=${1:-r03}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export PMC_TIMEOUT=${PMC_TIMEOUT:-150}
+run() { echo "== $*"; bash tools/collect_pmc.sh "$@" > /dev/null 2>&1 || { echo "collection failed: $*"; exit 1; }; }
+# the bench command itself (headline f64 kernel; the f32 fast path)
+run ${tag}_bench_f64 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-path --no-rng-named
+run ${tag}_bench_f32 bench.py --steps 3 --warmup 1 --no-cpu-baseline --precision f32
+# the clustering main, chain per lane (f64: chains in device memory), n = 100
+run ${tag}_cluster_f64_ni tools/profile_cluster.py ni f64 5000 2
+run ${tag}_cluster_f64_ising tools/profile_cluster.py ising f64 5000 2
+# the all-pairs kernels in f64: fixed-force main n = 64 (BASELINE configs[3]), clustering main n = 100
+run ${tag}_interacting_f64_n64 tools/profile_interacting.py 64 f64 4000 2
+run ${tag}_cluster_wave_f64_n100 tools/profile_cluster.py interacting f64 1000 2
+# the f64 Ising sweep at the phase-scan chain length
+run ${tag}_sweep_f64_ising_n200 tools/profile_sweep.py f64 200 65536 20000 2 2
+echo "collected"

@@ -1,0 +1,13 @@
+#!/bin/bash
+# gpurun_out/prof_<tag>_* (tools/collect_round_profiles.sh) -> profiles/<tag>/ and profiles/pmc_traffic.json
+set -euo pipefail
+tag=${1:-r03}
+S="python tools/summarize_pmc.py"
+$S gpurun_out/prof_${tag}_bench_f64 profiles/$tag bench_f64 --kernel sweep_kernel --updates 6553600000 --record f64_n100_c65536_s100000 > /dev/null
+$S gpurun_out/prof_${tag}_bench_f32 profiles/$tag bench_f32 --kernel sweep_kernel --updates 6553600000 --record f32_n100_c65536_s100000 > /dev/null
+$S gpurun_out/prof_${tag}_cluster_f64_ni profiles/$tag cluster_f64_ni --kernel cluster --updates 327680000 > /dev/null
+$S gpurun_out/prof_${tag}_cluster_f64_ising profiles/$tag cluster_f64_ising --kernel cluster --updates 327680000 > /dev/null
+$S gpurun_out/prof_${tag}_interacting_f64_n64 profiles/$tag interacting_f64_n64 --kernel interacting_kernel --updates 65536000 > /dev/null
+$S gpurun_out/prof_${tag}_cluster_wave_f64_n100 profiles/$tag cluster_wave_f64_n100 --kernel cluster_wave --updates 16384000 > /dev/null
+$S gpurun_out/prof_${tag}_sweep_f64_ising_n200 profiles/$tag sweep_f64_ising_n200 --kernel sweep_kernel --updates 1310720000 > /dev/null
+ls profiles/$tag
