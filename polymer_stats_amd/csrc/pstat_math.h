@@ -172,15 +172,23 @@ __device__ __forceinline__ float pair_term_fast(float rx, float ry, float rz, fl
   const float num = __builtin_fmaf(-3.0f * ir2, mir * mjr, mimj);
   return num * (ir2 * ir) * 0.0795774715459476679f;   // 1/(4 pi)
 }
+// 1 / sqrt(x) in full double precision from v_rsq_f64 (relative error 5.2e-8, measured) and ONE third-order correction:
+// with e = 1 - x y^2,  1/sqrt(x) = y / sqrt(1 - e) = y (1 + e/2 + 3 e^2 / 8 + O(e^3)),  e^3 ~ 1e-22.  Five instructions
+// where two Newton steps take eight (+3...5 % on the f64 all-pairs kernels); max error 2.6 ulp over 4 M arguments of
+// 1e-12 ... 1e12 (tools/mathcheck; the two Newton steps gave 1.2 ulp: the rounding of x y enters e).  rsq(0) = inf gives
+// x y = NaN and the result NaN: the callers' 1/r^3 singularity stays a NaN as in the reference.
+__device__ __forceinline__ double rsqrt_f64(const double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-(x * y), y, 1.0);
+  return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
+}
 __device__ __forceinline__ double pair_term_fast(double rx, double ry, double rz, double mix, double miy,
                                                  double miz, double mjx, double mjy, double mjz) {
-  // f64 hot loops: the same algebraic form as the f32 one, 1/r from v_rsq_f64 and two Newton steps (full double
-  // precision; ~30 instructions against ~75 for the literal sqrt + divisions of pair_term<double>, which the
-  // initialisation kernels keep).  r = 0 gives NaN, as the literal form does.
+  // f64 hot loops: the same algebraic form as the f32 one, 1/r from rsqrt_f64 (full double precision; ~27 instructions
+  // against ~75 for the literal sqrt + divisions of pair_term<double>, which the initialisation kernels keep).
+  // r = 0 gives NaN, as the literal form does.
   const double r2 = __builtin_fma(rz, rz, __builtin_fma(ry, ry, rx * rx));
-  double y = __builtin_amdgcn_rsq(r2);
-  y = __builtin_fma(0.5 * y, __builtin_fma(-r2 * y, y, 1.0), y);
-  y = __builtin_fma(0.5 * y, __builtin_fma(-r2 * y, y, 1.0), y);
+  const double y = rsqrt_f64(r2);
   const double ir2 = y * y;
   const double mimj = __builtin_fma(miz, mjz, __builtin_fma(miy, mjy, mix * mjx));
   const double mir = __builtin_fma(miz, rz, __builtin_fma(miy, ry, mix * rx));

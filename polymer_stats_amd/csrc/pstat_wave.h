@@ -53,15 +53,12 @@ __device__ __forceinline__ float pair_fast(float rx, float ry, float rz, float m
 __device__ __forceinline__ double pair_fast(double rx, double ry, double rz, double mix, double miy,
                                             double miz, double mjx, double mjy, double mjz) {
   // The term of inc/eap_chain.jl:200-207 without its final 1/(4 pi), in the algebraic form of the f32 version:
-  // [mu_i.mu_j - 3 (mu_i.r)(mu_j.r) / r^2] / r^3 with 1/r from v_rsq_f64 and two Newton steps (full double precision)
-  // instead of the literal sqrt + four divisions: ~30 instructions against ~75.  Rounding differs from the literal
+  // [mu_i.mu_j - 3 (mu_i.r)(mu_j.r) / r^2] / r^3 with 1/r from v_rsq_f64 and one third-order correction (rsqrt_f64,
+  // pstat_math.h: full double precision) instead of the literal sqrt + four divisions: ~27 instructions against ~75.  Rounding differs from the literal
   // form in the last bits only, which cannot move a chain off the oracle's trajectory (see sincos_fast_f64 in
   // pstat_math.h); r = 0 still gives NaN (inf * 0) and the proposal is rejected as in the reference.
   const double r2 = __builtin_fma(rz, rz, __builtin_fma(ry, ry, rx * rx));
-  double y = __builtin_amdgcn_rsq(r2);
-  const double h = 0.5 * y;
-  y = __builtin_fma(h, __builtin_fma(-r2 * y, y, 1.0), y);
-  y = __builtin_fma(0.5 * y, __builtin_fma(-r2 * y, y, 1.0), y);
+  const double y = rsqrt_f64(r2);
   const double ir2 = y * y;
   const double mimj = __builtin_fma(miz, mjz, __builtin_fma(miy, mjy, mix * mjx));
   const double mir = __builtin_fma(miz, rz, __builtin_fma(miy, ry, mix * rx));

@@ -20,9 +20,13 @@ __host__ __device__ inline double acos_arg(int i) {
   return (double)(((unsigned)i * 2654435761u) >> 8) / 8388608.0 - 1.0;
 }
 
-__global__ void run(const double *x, double *s, double *c, double *ex, double *lg, double *sf, double *cf, double *ac, int n) {
+// argument of the rsqrt check: r^2 from 1e-12 to 1e+12, log-spaced with a per-point mantissa jitter
+__host__ __device__ inline double rsq_arg(int i) { return exp(-27.6 + 55.2 * ((double)(i & 0xFFFFF) + 0.5) / 1048576.0) * (1.0 + 1e-3 * (double)(i % 997)); }
+
+__global__ void run(const double *x, double *s, double *c, double *ex, double *lg, double *sf, double *cf, double *ac, double *rq, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  rq[i] = pstat::rsqrt_f64(rsq_arg(i));             // 1/r of the f64 pair terms
   pstat::sincos_f64(x[i], &s[i], &c[i]);
   if (x[i] >= 0.0 && x[i] <= M_PI) pstat::sincos_fast_f64<true>(x[i], &sf[i], &cf[i]);   // the sweep's hot-loop form
   else pstat::sincos_fast_f64<false>(x[i], &sf[i], &cf[i]);
@@ -48,11 +52,12 @@ int main() {
   const double special[] = {0.0, M_PI, M_PI / 2, M_PI / 4, 3 * M_PI / 4, -M_PI, 2 * M_PI, 1e-300, 9e4, -7e4, std::nextafter(M_PI, 0.0), 1.0};
   const int nsp = (int)(sizeof special / sizeof *special);
   for (int i = 0; i < nsp; ++i) x[i] = special[i];
-  double *d[8];
+  double *d[9];
   for (auto &p : d) if (hipMalloc(&p, n * 8) != hipSuccess) return 2;
   if (hipMemcpy(d[0], x.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) return 2;
-  hipLaunchKernelGGL(run, dim3(n / 256), dim3(256), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], n);
-  std::vector<double> s(n), c(n), ex(n), lg(n), sf(n), cf(n), ac(n);
+  hipLaunchKernelGGL(run, dim3(n / 256), dim3(256), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], n);
+  std::vector<double> s(n), c(n), ex(n), lg(n), sf(n), cf(n), ac(n), rq(n);
+  if (hipMemcpy(rq.data(), d[8], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(ac.data(), d[7], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(sf.data(), d[5], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(cf.data(), d[6], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
@@ -60,7 +65,7 @@ int main() {
   if (hipMemcpy(c.data(), d[2], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(ex.data(), d[3], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
   if (hipMemcpy(lg.data(), d[4], n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 2;
-  double ms = 0, mc = 0, me = 0, ml = 0, msf = 0, mcf = 0, mac = 0;
+  double ms = 0, mc = 0, me = 0, ml = 0, msf = 0, mcf = 0, mac = 0, mrq = 0;
   int bad = 0;
   for (int i = 0; i < n; ++i) {
     const double es = ulps(s[i], sinl((long double)x[i])), ec = ulps(c[i], cosl((long double)x[i]));
@@ -79,6 +84,11 @@ int main() {
       mac = fmax(mac, ea);
       if (ea > 1.5) ++bad;
     }
+    {
+      const double er = ulps(rq[i], 1.0L / sqrtl((long double)rsq_arg(i)));
+      mrq = fmax(mrq, er);
+      if (er > 3.0) ++bad;
+    }
     const double a = fabs(x[i]);
     const double arg = -a * 0.007;                  // the same double the device saw
     const double ee = ulps(ex[i], expl((long double)arg));
@@ -87,6 +97,7 @@ int main() {
     if (ee > 2.0) ++bad;
   }
   printf("over %d arguments: max error sin %.3f ulp, cos %.3f ulp, exp %.3f ulp, log %.3f ulp; %d out of bounds\n", n, ms, mc, me, ml, bad);
+  printf("rsqrt_f64 (v_rsq_f64 + one third-order correction): max error %.3f ulp\n", mrq);
   printf("acos_r (f64): max error %.3f ulp; acos(1) = %g, acos(-1) = %.17g\n", mac, ac[0], ac[1]);
   printf("fast hot-loop form: max error sin %.3f, cos %.3f (ulp of the result, or units of 2^-53 next to a zero); sin(fl(pi)) = %.17g, "
          "cos(fl(pi/2)) = %.17g, sin(0) = %g\n", msf, mcf, sf[1], cf[2], sf[0]);
