@@ -440,3 +440,45 @@ def test_f64_cluster_state_in_memory_matches_state_in_lds(ps, monkeypatch):
     for n in (2, 40, 41):     # the default home is device memory at every chain length (the cache of n-hat pays everywhere)
         with ps.Ensemble(ps.default_params(num_chains=64, precision=ps.F64, n=n, move_set=ps.MOVES_CLUSTER)) as e:
             assert "state in memory" in e.launch_info().kernel.decode()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=100, E0=1.0, K1=0.0, K2=1.0, kT=1.0, adj_ub=0.40),                                  # the chain of run/Ising_2025-12-18.jl, disordered
+    dict(n=100, E0=1.0, K1=0.3, K2=0.05, kT=0.05, energy_type=2, bend_mod=0.5, adj_ub=0.40),  # cold and stiff: clusters run on for tens of monomers
+], ids=["disordered", "aligned"])
+def test_f64_cluster_homes_agree_at_scale(ps, monkeypatch, kw):
+    """Full-size ensembles of the two homes of the f64 cluster kernel under one protocol (annealing rung, then a recorded
+    run): independent samples of the SAME algorithm, so every pooled average -- 16 observables, acceptance ratio, <cos^2>,
+    <psi> -- must agree within 4.5 combined standard errors.  The aligned case drives what the bit-parity cases reach with
+    a handful of chains only: the ring-fed growth beyond the window and the member passes of long clusters, on 16 384
+    chains at once."""
+    out = {}
+    for where in ("lds", "global"):
+        monkeypatch.setenv("PSTAT_F64_STATE", where)
+        pp = ps.default_params(num_chains=16384, precision=ps.F64, seed=101 + len(out), move_set=ps.MOVES_CLUSTER,
+                               cluster_prob=0.5, **kw)
+        with ps.Ensemble(pp) as e:
+            assert ("state in memory" in e.launch_info().kernel.decode()) == (where == "global")
+            _run_gpu(e, pp, 12000, (10.0, 1.0), 4000)
+            s = e.summary()
+            assert s.nan_rejects == 0
+            out[where] = (np.r_[s.avg, s.extra_avg, s.acceptance_ratio], np.r_[s.stderr, s.extra_stderr, s.ar_stderr])
+    z = (out["global"][0] - out["lds"][0]) / np.sqrt(out["global"][1] ** 2 + out["lds"][1] ** 2 + 1e-300)
+    assert np.all(np.abs(z) < 4.5), (z, out["global"][0], out["lds"][0])
+
+
+def test_f64_cluster_in_memory_equilibrium_without_flips(ps, golden):
+    """cluster_prob = 1 (no flips): the clustering main is the plain single-move sampler plus two averagers, so after a
+    burn-in the default f64 kernel (chains in memory, cached n-hat) must sit on the closed form of BASELINE configs[1] at
+    Fz = 1 -- all 16 pooled averages within 5 of their own standard errors (~1e-4 relative on <r_z>)."""
+    eq = golden["cfg2_n100_E0_1_K1_1_Fz1"]["avg"]
+    pp = ps.default_params(n=100, E0=1.0, K1=1.0, K2=0.0, Fz=1.0, kT=1.0, num_chains=32768, seed=55, precision=ps.F64,
+                           move_set=ps.MOVES_CLUSTER, cluster_prob=1.0)
+    with ps.Ensemble(pp) as e:
+        assert "state in memory" in e.launch_info().kernel.decode()
+        e.advance(20000)
+        e.reset_averages()
+        e.advance(30000)
+        s = e.summary()
+    z = np.array([(s.avg[k] - eq[nm]) / (s.stderr[k] + 1e-12 * (1 + abs(eq[nm]))) for k, nm in enumerate(ps.OBS_NAMES)])
+    assert np.all(np.abs(z) < 5.0), dict(zip(ps.OBS_NAMES, np.round(z, 2)))

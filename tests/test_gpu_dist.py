@@ -77,6 +77,12 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
     bad = subprocess.run(cmd + ["--precision", "nonsense"], env=env, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and bad.stdout.strip() == ""
+    # RCCL with more ranks than GPUs: the rank without a device exits at once, the launcher stops the other one instead of
+    # leaving it in the rendezvous, and nothing is printed on stdout
+    import polymer_stats_amd as ps
+    if ps._lib.load().pstat_device_count() == 1:
+        over = subprocess.run([a if a != "gloo" else "nccl" for a in cmd], env=env, capture_output=True, text=True, timeout=300)
+        assert over.returncode != 0 and over.stdout.strip() == "" and "only 1 GPU(s) visible" in over.stderr
 
 
 def _scan(tmp_path, name, *extra, timeout=900):
