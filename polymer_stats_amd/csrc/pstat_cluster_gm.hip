@@ -272,8 +272,11 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       if constexpr (CELL == 40) { R ct0_; AG::sc_theta(th0, &st0, &ct0_); }   // (40-byte cells carry no sin(theta))
       const T3 n0{c0a.x, c0a.y, c0b.x};
       const R ct0 = n0.z;
-      const R ph1 = ph0 + phistep * sym11<R>(wphi);
-      const R th1 = fmin(PI, fmax((R)0, th0 + thstep * sym11<R>(wth)));
+      // (the trajectory itself: each product rounded before its sum, as the oracle and Julia round them -- through an opaque
+      // register, so that no build flag can fuse them; cf. run_segment)
+      auto rounded = [](R v) __attribute__((always_inline)) -> R { asm volatile("" : "+v"(v)); return v; };
+      const R ph1 = ph0 + rounded(phistep * sym11<R>(wphi));
+      const R th1 = fmin(PI, fmax((R)0, th0 + rounded(thstep * sym11<R>(wth))));
       R st1, ct1, sp1, cp1;
       AG::sc_theta(th1, &st1, &ct1);
       AG::sc_phi(ph1, &sp1, &cp1);

@@ -482,3 +482,28 @@ def test_f64_cluster_in_memory_equilibrium_without_flips(ps, golden):
         s = e.summary()
     z = np.array([(s.avg[k] - eq[nm]) / (s.stderr[k] + 1e-12 * (1 + abs(eq[nm]))) for k, nm in enumerate(ps.OBS_NAMES)])
     assert np.all(np.abs(z) < 5.0), dict(zip(ps.OBS_NAMES, np.round(z, 2)))
+
+
+def test_f64_cluster_in_memory_time_segments(ps, monkeypatch):
+    """The persistent (block, segment) queue under the in-memory kernel: every job co-resident (64 blocks x 3 or 7 segments),
+    later segments wait on their predecessors, each boundary spills the angles and refills the working buffer (the cached
+    n-hat is re-derived there).  Trajectories must equal the unsegmented launch's; the running sums agree to 1e-10 (a
+    reflected monomer's cached n_z is the mapped one until the next refill: an ulp)."""
+    pp = ps.default_params(num_chains=4096, precision=ps.F64, n=60, E0=1.0, K1=0.3, K2=0.05, Fz=0.4, seed=12, energy_type=ps.ISING,
+                           move_set=ps.MOVES_CLUSTER, cluster_prob=0.4, bend_mod=0.3, steps_per_adjust=700)
+    monkeypatch.setenv("PSTAT_MAX_SPINS", str(1 << 19))     # fail within ~1 s instead of hanging
+    states = {}
+    for nseg in ("1", "3", "7"):
+        monkeypatch.setenv("PSTAT_SEGMENTS", nseg)
+        with ps.Ensemble(pp) as e:
+            assert "state in memory" in e.launch_info().kernel.decode()
+            e.advance(4200)
+            e.sync()
+            states[nseg] = [e.chain_state(c) for c in (0, 63, 64, 1000, 4095)] + [e.reduce_host()]
+    for nseg in ("3", "7"):
+        for a, b in zip(states["1"][:-1], states[nseg][:-1]):
+            for k in ("theta", "phi", "rng"):
+                assert np.array_equal(a[k], b[k]), (nseg, k)
+            assert a["nacc_total"] == b["nacc_total"] and a["phi_step"] == b["phi_step"]
+            np.testing.assert_allclose(a["sums"], b["sums"], rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(states["1"][-1], states[nseg][-1], rtol=1e-10, atol=1e-8)
