@@ -69,6 +69,11 @@ constexpr int XREQ = PSTAT_GM_XREQ;
 #define PSTAT_GM_D 2
 #endif
 constexpr int D = PSTAT_GM_D;        // rows in flight per end once a cluster has outgrown those
+#ifndef PSTAT_GM_CAPT
+#define PSTAT_GM_CAPT 8
+#endif
+constexpr int CAPT = PSTAT_GM_CAPT;  // ring rounds that still capture the boundary monomers (a multiple of D)
+static_assert(CAPT % D == 0, "whole ring trips");
 static_assert(XREQ < W, "the outer rows are requested inside the window rounds");
 constexpr uint32_t OOB = 0x80000000u;  // past every working buffer (num_records < 2^31, checked by the host): no access
 
@@ -373,23 +378,43 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
           // ---- beyond: one end in 2^(W + E) gets here -- rarely in a disordered chain, every step in an aligned one
           // (cold or stiff: every link joins, clusters run to the chain ends).  A ring of D register sets, each row
           // requested D rounds before its round; the ring was first filled when these ends entered round W.
-          while (gu || gl) {
+          // The boundary monomers are captured round by round for the first CAPT rounds (a disordered chain's tail is a
+          // round or two: no further memory phase); an end that grows on drops the capture -- a fifth of the round's
+          // instructions, for tens of rounds -- and reads its two boundary monomers back when it has stopped.
+          auto ring_round = [&](const int k, const bool cap) __attribute__((always_inline)) {
+            const T3 Bu = nhat(ra[k], rb[k]), Bl = nhat(sa[k], sb[k]);
+            const bool eBu = is_edge(rb[k].y), eBl = is_edge(sb[k].y);
+            if (cap) capture(gu, Au, Bu, cu, nu);
+            half_round(true, gu, Au, Bu, eBu, upper_p, upper);
+            Au = Bu;
+            if (cap) capture(gl, Al, Bl, cl, nl);
+            half_round(false, gl, Al, Bl, eBl, lower_p, lower);
+            Al = Bl;
+            ring += 1;      // this set is free again: its next row is D rounds out
+            uint32_t q = up_off(idx + ring + D - 1, gu);
+            ra[k] = ld(q); rb[k] = ld(q + 16);
+            q = dn_off(idx - ring - D + 1, gl);
+            sa[k] = ld(q); sb[k] = ld(q + 16);
+          };
+          for (int trip = 0; trip < CAPT / D && (gu || gl); ++trip) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-              const T3 Bu = nhat(ra[k], rb[k]), Bl = nhat(sa[k], sb[k]);
-              const bool eBu = is_edge(rb[k].y), eBl = is_edge(sb[k].y);
-              capture(gu, Au, Bu, cu, nu);
-              half_round(true, gu, Au, Bu, eBu, upper_p, upper);
-              Au = Bu;
-              capture(gl, Al, Bl, cl, nl);
-              half_round(false, gl, Al, Bl, eBl, lower_p, lower);
-              Al = Bl;
-              ring += 1;      // this set is free again: its next row is D rounds out
-              uint32_t q = up_off(idx + ring + D - 1, gu);
-              ra[k] = ld(q); rb[k] = ld(q + 16);
-              q = dn_off(idx - ring - D + 1, gl);
-              sa[k] = ld(q); sb[k] = ld(q + 16);
+            for (int k = 0; k < D; ++k) ring_round(k, true);
+          }
+          const bool longu = gu, longl = gl;     // still growing after the captured rounds
+          if (__builtin_amdgcn_ballot_w64(longu || longl) != 0) {
+            while (gu || gl) {
+#pragma unroll
+              for (int k = 0; k < D; ++k) ring_round(k, false);
             }
+            uint32_t o = longu ? row_off(upper) : OOB;
+            v2dd ta = ld(o), tb = ld(o + 16);
+            cu.x = longu ? ta.x : cu.x; cu.y = longu ? ta.y : cu.y; cu.z = longu ? tb.x : cu.z;
+            o = (longu && upper < n - 1) ? row_off(upper + 1) : OOB; ta = ld(o); tb = ld(o + 16);
+            nu.x = longu ? ta.x : nu.x; nu.y = longu ? ta.y : nu.y; nu.z = longu ? tb.x : nu.z;
+            o = longl ? row_off(lower) : OOB; ta = ld(o); tb = ld(o + 16);
+            cl.x = longl ? ta.x : cl.x; cl.y = longl ? ta.y : cl.y; cl.z = longl ? tb.x : cl.z;
+            o = (longl && lower > 0) ? row_off(lower - 1) : OOB; ta = ld(o); tb = ld(o + 16);
+            nl.x = longl ? ta.x : nl.x; nl.y = longl ? ta.y : nl.y; nl.z = longl ? tb.x : nl.z;
           }
         }
         upper_p = upper >= n - 1 ? (R)0 : upper_p;   // ran into the chain end: no link to test, :282-284
