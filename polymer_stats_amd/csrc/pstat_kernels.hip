@@ -31,6 +31,12 @@
 #include "../../include/pstat.h"
 #include "pstat_math.h"
 
+#ifndef PSTAT_GI_DEPTH
+#define PSTAT_GI_DEPTH 1   // prefetch depth (steps) of the f64 Ising sweep with its cells in memory
+#endif
+#ifndef PSTAT_GI_CC
+#define PSTAT_GI_CC 1      // f64 Ising sweep with its cells in memory: chain-contiguous working buffer
+#endif
 #ifndef PSTAT_UNROLL_ISING
 #define PSTAT_UNROLL_ISING 16  // the Ising step is ~3x as long
 #endif
@@ -164,7 +170,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // GM pipeline depth: 2 steps for the non-interacting step; the Ising step is ~2.5x as long and fetches three rows (the
   // monomer and its two neighbours), so one step ahead gives its loads the same time and a third of the registers
   constexpr bool GI = GM && EN == PSTAT_ISING;
-  constexpr int DEPTH = GI ? 1 : 2;
+  constexpr int DEPTH = GI ? PSTAT_GI_DEPTH : 2;
   using Cell = typename std::conditional<Q, uint32_t, R2>::type;
   const int lanes = GM ? 64 : A.lanes;
   unsigned char *const cells = GM ? reinterpret_cast<unsigned char *>(S.work) + (size_t)blk * (size_t)A.n * 64 * sizeof(Cell) : smem;
@@ -201,6 +207,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       v.x = gth[(int64_t)i * C + c];
       v.y = gph[(int64_t)i * C + c];
       if (GM && i < A.lds_rows) reinterpret_cast<Cell *>(smem)[i * lanes + lane] = v;
+      else if constexpr (GM) *reinterpret_cast<Cell *>(cells + ((EN == PSTAT_ISING && PSTAT_GI_CC) ? (uint32_t)lane * (uint32_t)n * (uint32_t)sizeof(Cell) + (uint32_t)i * (uint32_t)sizeof(Cell)
+                                                                                                          : (uint32_t)(i * lanes + lane) * (uint32_t)sizeof(Cell))) = v;
       else ang[i * lanes + lane] = v;
     }
   }
@@ -242,6 +250,15 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   using P = typename V2<R>::type;   // a 2-vector: (x, y), {n_z, mu_z}, (theta, phi) or {old, new}
   const uint32_t row_bytes = (uint32_t)lanes * (uint32_t)sizeof(Cell), lane_bytes = (uint32_t)lane * (uint32_t)sizeof(Cell);
   auto slot = [&](uint32_t off) __attribute__((always_inline)) -> Cell & { return *reinterpret_cast<Cell *>(cells + off); };
+  // GM: where monomer idx of this lane's chain lives in the global working buffer.  [n][64] (a 1 KiB row per monomer)
+  // for the non-interacting step, which touches one cell; CHAIN-CONTIGUOUS [lane][n] for the Ising step (PSTAT_GI_CC),
+  // whose three cells -- the monomer and its two neighbours -- then share one or two 128-byte lines instead of
+  // lying in three rows (measured at n = 200: fabric traffic 267 -> ~120 bytes per update; the kernel was bound by it).
+  constexpr bool CC = GI && PSTAT_GI_CC;
+  const uint32_t chain_g = (uint32_t)lane * (uint32_t)n * (uint32_t)sizeof(Cell);
+  auto gofs = [&](const uint32_t idx) __attribute__((always_inline)) -> uint32_t {
+    return CC ? chain_g + idx * (uint32_t)sizeof(Cell) : idx * row_bytes + lane_bytes;
+  };
   // GM: rows [0, nL) of the wave's cells sit in LDS (as many as four resident waves per CU can share), the rest in
   // memory.  One CU sustains only about three waves' worth of divergent 16-byte accesses per step (measured: 3 waves per
   // CU run at full speed, the 4th stretches every step by 50 %), so every access kept on chip counts.  Which home a
@@ -262,7 +279,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
     const bool inL = idx < nL;
     RowG r;
     r.l = *reinterpret_cast<Cell *>(smem + (inL ? cell : trash));
-    r.g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, inL ? 0xFFFFFFFFu : cell, 0, 0);
+    r.g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, inL ? 0xFFFFFFFFu : gofs(idx), 0, 0);
     return r;
   };
   // a fetched cell at its first use: its home, then the commits made after its load was issued (fw2 older, fw1 newer)
@@ -306,7 +323,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       *reinterpret_cast<Cell *>(smem + ((ok && inL) ? d.cell : trash)) = v;
       typedef double v2dd __attribute__((ext_vector_type(2)));
       const v2dd vv = {v.x, v.y};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, vv), rsrc, (ok && !inL) ? d.cell : 0xFFFFFFFFu, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, vv), rsrc, (ok && !inL) ? gofs(d.idx) : 0xFFFFFFFFu, 0, 0);
     } else {
       slot(d.cell) = v;
     }
@@ -765,7 +782,10 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   } else {
     R *gth = (R *)S.ang, *gph = (R *)S.ang + (int64_t)n * C;
     for (int i = 0; i < n; ++i) {
-      const R2 v = (GM && i < A.lds_rows) ? reinterpret_cast<Cell *>(smem)[i * lanes + lane] : ang[i * lanes + lane];
+      R2 v;
+      if (GM && i < A.lds_rows) v = reinterpret_cast<Cell *>(smem)[i * lanes + lane];
+      else if constexpr (GM) v = *reinterpret_cast<Cell *>(cells + gofs((uint32_t)i));
+      else v = ang[i * lanes + lane];
       gth[(int64_t)i * C + c] = v.x;
       gph[(int64_t)i * C + c] = v.y;
     }
