@@ -39,7 +39,7 @@ CASES = [
      dict(n=100, E0=1.0, K1=1.0, Fz=1.0, num_chains=65536, precision=0, seed=1)),
     ("q16 sweep n=100", 1.6e11, 100000, "q16",
      dict(n=100, E0=1.0, K1=1.0, Fz=1.0, num_chains=65536, precision=2, seed=1)),
-    ("f64 Ising sweep n=200", 1.2e10, 20000, "state in L2",
+    ("f64 Ising sweep n=200", 2.0e10, 20000, "state in L2",      # round 3: chain-contiguous working buffer, 2.6e10 -> 4e10
      dict(n=200, E0=1.0, K1=1.0, kT=1.0, energy_type=2, num_chains=65536, precision=1, seed=1)),
     ("f64 all-pairs n=64", 1.6e8, 2000, "interacting_kernel<double>",
      dict(n=64, E0=1.0, K1=1.0, Fz=0.5, energy_type=1, num_chains=16384, precision=1, seed=1)),
