@@ -46,6 +46,28 @@ __global__ __launch_bounds__(64) void scatter_kernel(const double2 *__restrict__
   if (acc == 12345.678) out[0] = acc;
 }
 
+// the same scattered reads through a buffer resource with cache-policy bits (sc0 = 1, nt = 2, sc1 = 16): does any policy make
+// L2 request less than a whole 128-byte line from the fabric?
+typedef int v4i_ __attribute__((ext_vector_type(4)));
+template <int AUX>
+__global__ __launch_bounds__(64) void scatter_aux_kernel(const double2 *__restrict__ t, uint32_t rows, int per_lane, double *out) {
+  uint64_t s = 0x9E3779B97F4A7C15ull * (uint64_t)(blockIdx.x * 64 + threadIdx.x + 1);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)t, 0, 0x7FFFFFFF, 0x00020000);
+  int acc = 0;
+  for (int k = 0; k < per_lane; k += 4) {
+    v4i_ v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s = s * 6364136223846793005ull + 1442695040888963407ull;
+      const uint32_t r = (uint32_t)(((s >> 32) * (uint64_t)rows) >> 32);
+      v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (r * 64u + threadIdx.x) * 16u, 0, AUX);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += v[j].x ^ v[j].w;
+  }
+  if (acc == 0x12345678) out[0] = acc;
+}
+
 int main() {
   const size_t bytes = (size_t)2 << 30;                       // 2 GiB table: 8x the Infinity Cache
   const size_t cells = bytes / sizeof(double2);
@@ -62,6 +84,12 @@ int main() {
     CHECK(hipDeviceSynchronize());
     hipLaunchKernelGGL(scatter_kernel, dim3(waves), dim3(64), 0, 0, t, rows, per_lane, out);
     CHECK(hipDeviceSynchronize());
+  }
+  {   // policy variants on the first 1 GiB of the table (buffer offsets are 32-bit), warm-up + measured dispatch each
+    const uint32_t rows1 = (uint32_t)(((size_t)1 << 30) / 1024);
+#define RUN_AUX(A) for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(scatter_aux_kernel<A>, dim3(waves), dim3(64), 0, 0, t, rows1, per_lane / 4, out); CHECK(hipDeviceSynchronize()); }
+    RUN_AUX(0) RUN_AUX(1) RUN_AUX(2) RUN_AUX(3) RUN_AUX(16) RUN_AUX(17) RUN_AUX(18) RUN_AUX(19)
+    printf("fetch_calib: scatter_aux_kernel<AUX> makes %.6g accesses of 16 B each (AUX = sc0 | nt << 1 | sc1 << 4)\n", (double)waves * 64 * (per_lane / 4));
   }
   const double accesses = (double)waves * 64 * per_lane;
   printf("fetch_calib: stream_kernel reads %.6g bytes (16 B per lane, coalesced, each cell once)\n", (double)bytes);

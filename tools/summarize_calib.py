@@ -11,14 +11,17 @@ src, out = sys.argv[1], sys.argv[2]
 per = collections.defaultdict(lambda: collections.defaultdict(dict))
 for fn in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(fn)):
-        k = "stream" if "stream_kernel" in r["Kernel_Name"] else ("scatter" if "scatter_kernel" in r["Kernel_Name"] else None)
+        name = r["Kernel_Name"]
+        k = "stream" if "stream_kernel" in name else ("scatter" if "scatter_kernel" in name else None)
+        if "scatter_aux_kernel<" in name:
+            k = "scatter_aux<" + name.split("scatter_aux_kernel<")[1].split(">")[0] + ">"
         if k is None:
             continue
         d = per[k][r["Counter_Name"]]
         d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
 lines = [open(os.path.join(src, "stdout.txt")).read().strip(),
          "# counters: second dispatch of each kernel (the first is the warm-up); rocprofv3 --pmc, one group per run"]
-for k in ("stream", "scatter"):
+for k in ["stream", "scatter"] + sorted((x for x in per if x.startswith("scatter_aux")), key=lambda x: int(x.split("<")[1][:-1])):
     m = {c: v[max(v)] for c, v in per[k].items()}
     lines.append(f"{k}_kernel: " + "  ".join(f"{c}={m[c]:.6g}" for c in sorted(m)))
     if "FETCH_SIZE" in m:
