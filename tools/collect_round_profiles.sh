@@ -20,4 +20,5 @@ run ${tag}_interacting_f64_n64 tools/profile_interacting.py 64 f64 4000 2
 run ${tag}_cluster_wave_f64_n100 tools/profile_cluster.py interacting f64 1000 2
 # the f64 Ising sweep at the phase-scan chain length
 run ${tag}_sweep_f64_ising_n200 tools/profile_sweep.py f64 200 65536 20000 2 2
+run ${tag}_sweep_f64_ni_n200 tools/profile_sweep.py f64 200 65536 50000 2 0
 echo "collected"

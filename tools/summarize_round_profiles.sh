@@ -10,4 +10,9 @@ $S gpurun_out/prof_${tag}_cluster_f64_ising profiles/$tag cluster_f64_ising --ke
 $S gpurun_out/prof_${tag}_interacting_f64_n64 profiles/$tag interacting_f64_n64 --kernel interacting_kernel --updates 65536000 > /dev/null
 $S gpurun_out/prof_${tag}_cluster_wave_f64_n100 profiles/$tag cluster_wave_f64_n100 --kernel cluster_wave --updates 16384000 > /dev/null
 $S gpurun_out/prof_${tag}_sweep_f64_ising_n200 profiles/$tag sweep_f64_ising_n200 --kernel sweep_kernel --updates 1310720000 > /dev/null
+
+if [ -d gpurun_out/prof_${tag}_sweep_f64_ni_n200 ]; then
+  $S gpurun_out/prof_${tag}_sweep_f64_ni_n200 profiles/$tag sweep_f64_ni_n200 --kernel sweep_kernel --updates 3276800000 > /dev/null
+fi
+if [ -f gpurun_out/calib/stdout.txt ]; then python tools/summarize_calib.py gpurun_out/calib profiles/$tag/fetch_calib.txt > /dev/null; fi
 ls profiles/$tag
