@@ -270,7 +270,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   for (auto &c : h->cases) any_fx = any_fx || c.Fx != 0.0;
   h->cfg = {h->base.precision, h->base.chain_type, h->base.energy_type, h->base.do_flips ? 1 : 0,
             h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, 0, h->base.rng, h->base.move_set, 0};
-  h->cfg.state_global = f64_state_global(h->cfg, h->base.n) ? 1 : 0;
+  h->cfg.state_global = f64_state_global(h->cfg, h->base.n, (int64_t)ncases * h->base.num_chains) ? 1 : 0;
 
   const bool inter = all_pairs(h->base.energy_type);
   int lanes = (inter || h->cfg.state_global) ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
@@ -413,7 +413,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   const size_t nstate = h->bufs.size();
   CREATE_TRY(alloc(h, &S.ang_tmp, 2 * n * Cz * h->elem));
   if (cluster_gm)            // working copy of the chains, [chain block][lane][n] 48-byte cells (pstat_cluster_gm.hip)
-    CREATE_TRY(alloc(h, &S.work, cluster_gm_work_bytes(A)));
+    CREATE_TRY(alloc(h, &S.work, cluster_gm_work_bytes(h->cfg, A)));
   else if (h->cfg.state_global)   // working copy of the cells, [chain block][n][64] double2 (run_segment, ST = 2)
     CREATE_TRY(alloc(h, &S.work, (size_t)(A.blocks_per_case * ncases) * n * 64 * 16));
   CREATE_TRY(alloc(h, (void **)&h->d_cases, sizeof(CaseConst) * (size_t)ncases));

@@ -1,7 +1,10 @@
-// pstat_cluster_gm.hip -- the f64 step of mcmc_clustering_eap_chain.jl:268-311 with the chain state in DEVICE MEMORY.
+// pstat_cluster_gm.hip -- the step of mcmc_clustering_eap_chain.jl:268-311 with the chain state in DEVICE MEMORY: the f64 kernel
+// of that main (every chain length), and its f32 sibling for ensembles LDS cannot seat (f64_state_global(), pstat_kernels.hip).
 //
-// Same step, stream contract and results as cluster_kernel<double> of pstat_cluster.hip (one chain per lane, the
+// Same step, stream contract and results as cluster_kernel<R> of pstat_cluster.hip (one chain per lane, the
 // persistent (block, segment) job queue); what differs is where a chain lives while a segment runs and what a cell holds.
+// The text below describes the f64 instantiation; f32 keeps the same five values per cell in turns (20 bytes), its sincos
+// are two instructions (v_sin/v_cos) and its running totals are re-derived at every segment start like the LDS kernel's.
 //
 //   * An f64 (theta, phi) cell is 16 bytes, so LDS seats 160 KiB / (16 n) chains per CU: 102 at n = 100, 51 at n = 200 --
 //     a quarter (an eighth) of the 256 lanes of a CU's four SIMDs.  Here the cells live in DevState::work, laid out
@@ -35,6 +38,8 @@
 // starts and spilled to it when it ends, exactly as the LDS variants do.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pstat_cluster_common.h"
 #include "pstat_device.h"
 #include "pstat_math.h"
@@ -44,7 +49,9 @@ namespace pstat {
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 typedef double v2dd __attribute__((ext_vector_type(2)));
+typedef float v2ff __attribute__((ext_vector_type(2)));
 
 #ifndef PSTAT_GM_LDAUX
 #define PSTAT_GM_LDAUX 0   // cache-policy bits of the working buffer's loads / stores (sc0 = 1, nt = 2, sc1 = 16)
@@ -52,7 +59,8 @@ typedef double v2dd __attribute__((ext_vector_type(2)));
 #ifndef PSTAT_GM_STAUX
 #define PSTAT_GM_STAUX 0
 #endif
-constexpr uint32_t CELL = PSTAT_CLUSTER_GM_CELL;   // bytes per monomer
+// bytes per monomer: f64 [n_x, n_y | n_z, theta | phi] = 40; f32 the same five values in turns = 20
+template <typename R> constexpr uint32_t cell_bytes() { return sizeof(R) == 8 ? PSTAT_CLUSTER_GM_CELL : 20u; }
 #ifndef PSTAT_GM_W
 #define PSTAT_GM_W 3
 #endif
@@ -77,87 +85,79 @@ static_assert(CAPT % D == 0, "whole ring trips");
 static_assert(XREQ < W, "the outer rows are requested inside the window rounds");
 constexpr uint32_t OOB = 0x80000000u;  // past every working buffer (num_records < 2^31, checked by the host): no access
 
-template <typename G, int CT, int EN>
+template <typename R, typename G, int CT, int EN>
 __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const DevState &S, const CaseConst &cc,
                                                        const int umb_on, const int lane, const int64_t c, int64_t step,
                                                        int64_t remaining, const int blk) {
-  using R = double;
   using AG = Ang<R>;
   using T3 = V3<R>;
+  using P2 = typename std::conditional<sizeof(R) == 8, v2dd, v2ff>::type;   // half a row: (n_x, n_y) or (n_z, theta)
+  constexpr uint32_t CELL = cell_bytes<R>();
+  constexpr uint32_t HB = 2 * sizeof(R);                                      // bytes of such a half
   const int lanes = A.lanes;
   const int64_t C = S.C;
   const int n = (int)A.n;
   constexpr R PI = AG::theta_max;
 
-  const R Fz = cc.Fz, Fx = cc.Fx, b = cc.b, kT = cc.kT;
-  const R a_or_mu = (CT == PSTAT_DIELECTRIC) ? (cc.K1 - cc.K2) * cc.E0 : cc.mu;
-  const R k2e = cc.K2 * cc.E0;
-  const R mhalfE0 = -0.5 * cc.E0;
-  const R hb = -cc.b / 2;
-  const R khalf = cc.kappa / 2, psi0 = cc.psi0;
-  const R cprob = cc.cluster_prob;
-  (void)hb;
+  const R Fz = (R)cc.Fz, Fx = (R)cc.Fx, b = (R)cc.b, kT = (R)cc.kT;
+  const R a_or_mu = (CT == PSTAT_DIELECTRIC) ? (R)((cc.K1 - cc.K2) * cc.E0) : (R)cc.mu;
+  const R k2e = (R)(cc.K2 * cc.E0);
+  const R mhalfE0 = (R)(-0.5 * cc.E0);
+  const R hb = (R)(-cc.b / 2);
+  const R khalf = (R)(cc.kappa / 2), psi0 = (R)cc.psi0;
+  const R cprob = (R)cc.cluster_prob;
+  const R nbeta_log2e = (R)(-1.4426950408889634 / cc.kT);
+  (void)hb; (void)nbeta_log2e; (void)kT;
 
   // ---- the wave's working buffer: [lane][monomer] cells of this chain block
   const uint32_t chain_bytes = (uint32_t)n * CELL;
   unsigned char *const wbase = reinterpret_cast<unsigned char *>(S.work) + (size_t)blk * (size_t)lanes * chain_bytes;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wbase, 0, (int)((uint32_t)lanes * chain_bytes), 0x00020000);
   const uint32_t lb = (uint32_t)lane * chain_bytes;
-  auto ld = [&](const uint32_t off) __attribute__((always_inline)) -> v2dd {
-    return __builtin_bit_cast(v2dd, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, PSTAT_GM_LDAUX));
+  auto ld = [&](const uint32_t off) __attribute__((always_inline)) -> P2 {     // half a row
+    if constexpr (sizeof(R) == 8) return __builtin_bit_cast(P2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, PSTAT_GM_LDAUX));
+    else return __builtin_bit_cast(P2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, PSTAT_GM_LDAUX));
   };
   auto st = [&](const uint32_t off, const R x, const R y) __attribute__((always_inline)) {
-    const v2dd v = {x, y};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), rsrc, off, 0, PSTAT_GM_STAUX);
+    const P2 v = {x, y};
+    if constexpr (sizeof(R) == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), rsrc, off, 0, PSTAT_GM_STAUX);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), rsrc, off, 0, PSTAT_GM_STAUX);
   };
-  auto ld8 = [&](const uint32_t off) __attribute__((always_inline)) -> R {
-    return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, PSTAT_GM_LDAUX));
+  auto ld8 = [&](const uint32_t off) __attribute__((always_inline)) -> R {      // phi
+    if constexpr (sizeof(R) == 8) return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, PSTAT_GM_LDAUX));
+    else return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, PSTAT_GM_LDAUX));
   };
   auto st8 = [&](const uint32_t off, const R x) __attribute__((always_inline)) {
-    typedef int v2i __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, x), rsrc, off, 0, PSTAT_GM_STAUX);
+    if constexpr (sizeof(R) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, x), rsrc, off, 0, PSTAT_GM_STAUX);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, x), rsrc, off, 0, PSTAT_GM_STAUX);
   };
   auto row_off = [&](const int row) __attribute__((always_inline)) -> uint32_t { return lb + (uint32_t)row * CELL; };
 
-  // ---- fill: angles from the checkpoint planes (coalesced over the lanes), the cached trigonometry derived from them
-  // with the same functions the step uses for a moved monomer
-  {
-    const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
-#pragma unroll 2
-    for (int i = 0; i < n; ++i) {
-      const R th = gth[(int64_t)i * C + c], ph = gph[(int64_t)i * C + c];
-      R s, co, sp, cp;
-      AG::sc_theta(th, &s, &co);
-      AG::sc_phi(ph, &sp, &cp);
-      const uint32_t o = row_off(i);
-      st(o, cp * s, sp * s);
-      st(o + 16, co, th);
-      if constexpr (CELL == 40) st8(o + 32, ph); else st(o + 32, ph, s);
-    }
-  }
   G g;
   g.load(S.rng + c, C);
-  double phistep = S.stepsz[0 * C + c], thstep = S.stepsz[1 * C + c];
+  double phistep = S.stepsz[0 * C + c], thstep = S.stepsz[1 * C + c];    // radians, f64, like the reference (adaptation)
+  R phs = (R)(phistep / AG::unit), ths = (R)(thstep / AG::unit);          // in the unit the angles are stored in
   int64_t nacc_off = S.win[0 * C + c], natt_off = S.win[1 * C + c];
   int nacc_seg = 0, steps_seg = 0;
   int nnan_seg = 0;   // proposals with a non-finite energy difference (Ising pair terms at r -> 0)
-  R Orx = S.obs[OBS_R1 * C + c], Ory = S.obs[OBS_R2 * C + c], Orz = S.obs[OBS_R3 * C + c];
-  R Opx = S.obs[OBS_P1 * C + c], Opy = S.obs[OBS_P2 * C + c], Opz = S.obs[OBS_P3 * C + c];
-  R OU = S.obs[OBS_U * C + c];
-  R usum = S.obs[OBS_USUM * C + c];      // sum of u_i INCLUDING the bending terms (eap_chain.jl:53-58)
-  R c2sum = S.obs[OBS_C2 * C + c], psisum = S.obs[OBS_PSI * C + c];
+  R Orx = (R)S.obs[OBS_R1 * C + c], Ory = (R)S.obs[OBS_R2 * C + c], Orz = (R)S.obs[OBS_R3 * C + c];
+  R Opx = (R)S.obs[OBS_P1 * C + c], Opy = (R)S.obs[OBS_P2 * C + c], Opz = (R)S.obs[OBS_P3 * C + c];
+  R OU = (R)S.obs[OBS_U * C + c];
+  R usum = (R)S.obs[OBS_USUM * C + c];      // sum of u_i INCLUDING the bending terms (eap_chain.jl:53-58)
+  R c2sum = (R)S.obs[OBS_C2 * C + c], psisum = (R)S.obs[OBS_PSI * C + c];
   // log(alpha) of the last accepted proposal of this mcmc() call (inc/acceptance.jl:33-36), kept as alpha itself
   // (`lag_alpha`, lag_pending) until a literal evaluation or the spill needs the logarithm
-  R lag = S.lag[c], lag_alpha = 1;
+  R lag = (R)S.lag[c], lag_alpha = 1;
   bool lag_pending = false;
   const bool umb = umb_on != 0;
-  const R wscale = umb ? (0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT : 0.0;
-  const R uref = umb ? S.uref[c] : 0.0;
+  const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
+  const R uref = umb ? (R)S.uref[c] : (R)0;
   double wnorm = umb ? S.wnorm[c] : 0.0;
   // (the f64 running sums stay in HBM: a block of FLUSH steps is added to them at a time -- 32 registers that the
   // step's window needs more)
-  const R inv_nm1 = n > 1 ? 1.0 / (double)(n - 1) : 0.0;
-  const R ninv_kT = -1.0 / kT;
+  const R inv_nm1 = n > 1 ? (R)(1.0 / (double)(n - 1)) : (R)0;
+  const R ninv_kT = (R)(-1.0 / cc.kT);
+  (void)ninv_kT;
 
   const int64_t spa = A.steps_per_adjust;
   int64_t to_adj = A.adaptive ? spa - (step % spa) : 0;
@@ -180,7 +180,10 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
     else sm.z += q;
   };
   // reflection through the plane normal to the field: refl_n!, inc/eap_chain.jl:263-265
-  auto refl_theta = [&](const R th) __attribute__((always_inline)) -> R { return fmin(PI, fmax((R)0, th + (PI - 2 * th))); };
+  auto refl_theta = [&](const R th) __attribute__((always_inline)) -> R {
+    if constexpr (sizeof(R) == 8) return fmin(PI, fmax((R)0, th + (PI - 2 * th)));    // the reference's arithmetic
+    else return PI - th;
+  };
   auto refl_n = [](const T3 &v) __attribute__((always_inline)) -> T3 { return T3{v.x, v.y, -v.z}; };
   auto refl_mu = [](const T3 &m) __attribute__((always_inline)) -> T3 {
     if constexpr (CT == PSTAT_DIELECTRIC) return T3{-m.x, -m.y, m.z};   // a nz (nx, ny, nz) + k2e z
@@ -197,6 +200,47 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
     else epair = 0;
   };
 
+  // ---- fill: angles from the checkpoint planes (coalesced over the lanes), the cached trigonometry derived from them
+  // with the same functions the step uses for a moved monomer.  f32 carries r, p, U, sum(u), sum(psi), sum cos^2 as running
+  // totals of accepted differences, whose rounding errors random-walk: they are re-derived here, at every segment start
+  // (<= 32 768 steps apart in f32), from the angles being filled in, as the LDS kernel does.
+  {
+    const R *gth = (const R *)S.ang, *gph = (const R *)S.ang + (int64_t)n * C;
+    double tx = 0, ty = 0, tz = 0, qx = 0, qy = 0, qz = 0, tu = 0, tp = 0, tpsi = 0, tc2 = 0;
+    T3 pn{0, 0, 1}, pm{0, 0, 0};
+    (void)pn; (void)pm;
+#pragma unroll 2
+    for (int i = 0; i < n; ++i) {
+      const R th = gth[(int64_t)i * C + c], ph = gph[(int64_t)i * C + c];
+      R s, co, sp, cp;
+      AG::sc_theta(th, &s, &co);
+      AG::sc_phi(ph, &sp, &cp);
+      const uint32_t o = row_off(i);
+      st(o, cp * s, sp * s);
+      st(o + HB, co, th);
+      st8(o + 2 * HB, ph);
+      if constexpr (sizeof(R) == 4) {
+        const T3 ni{cp * s, sp * s, co}, mi = mu_of(ni);
+        tx += (double)ni.x; ty += (double)ni.y; tz += (double)ni.z;
+        qx += (double)mi.x; qy += (double)mi.y; qz += (double)mi.z;
+        tu += (double)(mhalfE0 * mi.z);
+        tc2 += (double)(ni.z * ni.z);
+        if (i > 0) {
+          R psi, eb, ep;
+          bond(pn, pm, ni, mi, psi, eb, ep);
+          tpsi += (double)psi; tu += (double)eb; tp += (double)ep;
+        }
+        pn = ni; pm = mi;
+      }
+    }
+    if constexpr (sizeof(R) == 4) {
+      const double bd = (double)b;
+      Orx = (R)(bd * tx); Ory = (R)(bd * ty); Orz = (R)(bd * tz);
+      Opx = (R)qx; Opy = (R)qy; Opz = (R)qz;
+      usum = (R)tu; psisum = (R)tpsi; c2sum = (R)tc2;
+      OU = (R)(tu + tp - ((double)Fx * bd * tx + (double)Fz * bd * tz));
+    }
+  }
   auto up_off = [&](const int row, const bool want) __attribute__((always_inline)) -> uint32_t {
     return (want && row <= n - 1) ? row_off(row) : OOB;
   };
@@ -207,7 +251,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
   // ---- the draws whose place in the stream is fixed (mcmc_clustering_eap_chain.jl:269-272 and the skip draw of
   // cluster_flip!, inc/eap_chain.jl:276) and the WINDOW they address
   struct Draw { int idx; uint32_t wphi, wth; bool flipped; };
-  struct Win { v2dd c0a, c0b, c0c, ua[W + 1], ub[W + 1], da[W + 1], db[W + 1]; };
+  struct Win { P2 c0a, c0b, c0c, ua[W + 1], ub[W + 1], da[W + 1], db[W + 1]; };
   auto draw_next = [&]() __attribute__((always_inline)) -> Draw {
     Draw d;
     d.idx = (int)__umulhi(g.next(), (uint32_t)n);
@@ -217,17 +261,17 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
   };
   auto request = [&](const Draw &d, Win &w) __attribute__((always_inline)) {
     const uint32_t off0 = row_off(d.idx);
-    w.c0a = ld(off0); w.c0b = ld(off0 + 16);
-    if constexpr (CELL == 40) w.c0c = v2dd{ld8(off0 + 32), 0.0}; else w.c0c = ld(off0 + 32);
+    w.c0a = ld(off0); w.c0b = ld(off0 + HB);
+    w.c0c = P2{ld8(off0 + 2 * HB), (R)0};
     const uint32_t offR = d.idx + 1 < n ? off0 + CELL : off0, offL = d.idx > 0 ? off0 - CELL : off0;
-    w.ua[1] = ld(offR); w.ub[1] = ld(offR + 16);
-    w.da[1] = ld(offL); w.db[1] = ld(offL + 16);
+    w.ua[1] = ld(offR); w.ub[1] = ld(offR + HB);
+    w.da[1] = ld(offL); w.db[1] = ld(offL + HB);
 #pragma unroll
     for (int k = 2; k <= W; ++k) {
       uint32_t o = up_off(d.idx + k, d.flipped);
-      w.ua[k] = ld(o); w.ub[k] = ld(o + 16);
+      w.ua[k] = ld(o); w.ub[k] = ld(o + HB);
       o = dn_off(d.idx - k, d.flipped);
-      w.da[k] = ld(o); w.db[k] = ld(o + 16);
+      w.da[k] = ld(o); w.db[k] = ld(o + HB);
     }
   };
 #ifdef PSTAT_GM_PROF   // (timing experiment: wave clocks of the step's phases, printed by one wave per launch)
@@ -263,31 +307,31 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       // the buffer.  Rows W + 1 .. W + E (`x*`) follow after growth round XREQ, asked for by the ends still growing
       // then (one in four), and serve rounds W .. W + E - 1 the same way.
       const uint32_t off0 = row_off(idx);
-      const v2dd c0a = w.c0a, c0b = w.c0b, c0c = w.c0c;
-      v2dd ua[W + E + 1], ub[W + E + 1], da[W + E + 1], db[W + E + 1];   // [k]: row idx + k / idx - k (a = n_x, n_y; b = n_z, theta)
+      const P2 c0a = w.c0a, c0b = w.c0b, c0c = w.c0c;
+      P2 ua[W + E + 1], ub[W + E + 1], da[W + E + 1], db[W + E + 1];   // [k]: row idx + k / idx - k (a = n_x, n_y; b = n_z, theta)
 #pragma unroll
       for (int k = 1; k <= W; ++k) { ua[k] = w.ua[k]; ub[k] = w.ub[k]; da[k] = w.da[k]; db[k] = w.db[k]; }
 #pragma unroll
-      for (int k = W + 1; k <= W + E; ++k) { ua[k] = ub[k] = da[k] = db[k] = v2dd{0, 0}; }
+      for (int k = W + 1; k <= W + E; ++k) { ua[k] = ub[k] = da[k] = db[k] = P2{0, 0}; }
 
       PF_MARK(0);   // window requested and landed (behind the preceding commit's stores)
       // ---- the single-monomer part
       const R th0 = c0b.y, ph0 = c0c.x;
       R st0 = c0c.y;
-      if constexpr (CELL == 40) { R ct0_; AG::sc_theta(th0, &st0, &ct0_); }   // (40-byte cells carry no sin(theta))
+      { R ct0_; AG::sc_theta(th0, &st0, &ct0_); }   // (the cell carries no sin(theta): 8 bytes per monomer matter, see the header)
       const T3 n0{c0a.x, c0a.y, c0b.x};
       const R ct0 = n0.z;
       // (the trajectory itself: each product rounded before its sum, as the oracle and Julia round them -- through an opaque
       // register, so that no build flag can fuse them; cf. run_segment)
       auto rounded = [](R v) __attribute__((always_inline)) -> R { asm volatile("" : "+v"(v)); return v; };
-      const R ph1 = ph0 + rounded(phistep * sym11<R>(wphi));
-      const R th1 = fmin(PI, fmax((R)0, th0 + rounded(thstep * sym11<R>(wth))));
+      const R ph1 = AG::wrap(ph0 + rounded(phs * sym11<R>(wphi)));
+      const R th1 = fmin(PI, fmax((R)0, th0 + rounded(ths * sym11<R>(wth))));
       R st1, ct1, sp1, cp1;
       AG::sc_theta(th1, &st1, &ct1);
       AG::sc_phi(ph1, &sp1, &cp1);
       const T3 n1{cp1 * st1, sp1 * st1, ct1};
       const T3 m0 = mu_of(n0), m1 = mu_of(n1);
-      auto nhat = [](const v2dd &a, const v2dd &b_) __attribute__((always_inline)) -> T3 { return T3{a.x, a.y, b_.x}; };
+      auto nhat = [](const P2 &a, const P2 &b_) __attribute__((always_inline)) -> T3 { return T3{a.x, a.y, b_.x}; };
       const T3 nL = nhat(da[1], db[1]), nR = nhat(ua[1], ub[1]);
       const T3 mL = mu_of(nL), mR = mu_of(nR);
 
@@ -337,9 +381,9 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
 #pragma unroll
             for (int k = W + 1; k <= W + E; ++k) {
               uint32_t q = up_off(idx + k, gu);
-              ua[k] = ld(q); ub[k] = ld(q + 16);
+              ua[k] = ld(q); ub[k] = ld(q + HB);
               q = dn_off(idx - k, gl);
-              da[k] = ld(q); db[k] = ld(q + 16);
+              da[k] = ld(q); db[k] = ld(q + HB);
             }
           }
         }
@@ -355,14 +399,14 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
         }
         if (__builtin_amdgcn_ballot_w64(gu || gl) != 0) {
           // (the ring of the rounds beyond W + E - 1, see below: rows W + E + 1 .. W + E + D, asked for by the ends that enter round W)
-          v2dd ra[D], rb[D], sa[D], sb[D];
+          P2 ra[D], rb[D], sa[D], sb[D];
           int ring = W + E + 1;      // row offset of ring set 0's current row
 #pragma unroll
           for (int k = 0; k < D; ++k) {
             uint32_t q = up_off(idx + ring + k, gu);
-            ra[k] = ld(q); rb[k] = ld(q + 16);
+            ra[k] = ld(q); rb[k] = ld(q + HB);
             q = dn_off(idx - ring - k, gl);
-            sa[k] = ld(q); sb[k] = ld(q + 16);
+            sa[k] = ld(q); sb[k] = ld(q + HB);
           }
           // ---- rounds W .. W + E - 1, out of the rows requested after round XREQ
 #pragma unroll
@@ -392,9 +436,9 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
             Al = Bl;
             ring += 1;      // this set is free again: its next row is D rounds out
             uint32_t q = up_off(idx + ring + D - 1, gu);
-            ra[k] = ld(q); rb[k] = ld(q + 16);
+            ra[k] = ld(q); rb[k] = ld(q + HB);
             q = dn_off(idx - ring - D + 1, gl);
-            sa[k] = ld(q); sb[k] = ld(q + 16);
+            sa[k] = ld(q); sb[k] = ld(q + HB);
           };
           for (int trip = 0; trip < CAPT / D && (gu || gl); ++trip) {
 #pragma unroll
@@ -407,13 +451,13 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
               for (int k = 0; k < D; ++k) ring_round(k, false);
             }
             uint32_t o = longu ? row_off(upper) : OOB;
-            v2dd ta = ld(o), tb = ld(o + 16);
+            P2 ta = ld(o), tb = ld(o + HB);
             cu.x = longu ? ta.x : cu.x; cu.y = longu ? ta.y : cu.y; cu.z = longu ? tb.x : cu.z;
-            o = (longu && upper < n - 1) ? row_off(upper + 1) : OOB; ta = ld(o); tb = ld(o + 16);
+            o = (longu && upper < n - 1) ? row_off(upper + 1) : OOB; ta = ld(o); tb = ld(o + HB);
             nu.x = longu ? ta.x : nu.x; nu.y = longu ? ta.y : nu.y; nu.z = longu ? tb.x : nu.z;
-            o = longl ? row_off(lower) : OOB; ta = ld(o); tb = ld(o + 16);
+            o = longl ? row_off(lower) : OOB; ta = ld(o); tb = ld(o + HB);
             cl.x = longl ? ta.x : cl.x; cl.y = longl ? ta.y : cl.y; cl.z = longl ? tb.x : cl.z;
-            o = (longl && lower > 0) ? row_off(lower - 1) : OOB; ta = ld(o); tb = ld(o + 16);
+            o = (longl && lower > 0) ? row_off(lower - 1) : OOB; ta = ld(o); tb = ld(o + HB);
             nl.x = longl ? ta.x : nl.x; nl.y = longl ? ta.y : nl.y; nl.z = longl ? tb.x : nl.z;
           }
         }
@@ -478,13 +522,20 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       // draws, the literal expression the rest.  The cached log(alpha) of the last acceptance enters the filter as the
       // factor alpha itself (no logarithm on the common path).
       const R dw = umb ? dus * wscale : (R)0;
-      bool ok = metropolis_filter(dU * ninv_kT + (dw - (lag_pending ? (R)0 : lag)), st1 * alpha,
-                                  st0 * (lag_pending ? lag_alpha : (R)1), weps, [&]() -> bool {
+      bool ok;
+      if constexpr (sizeof(R) == 8) {
+        ok = metropolis_filter(dU * ninv_kT + (dw - (lag_pending ? (R)0 : lag)), st1 * alpha,
+                               st0 * (lag_pending ? lag_alpha : (R)1), weps, [&]() -> bool {
+          const R lg = lag_pending ? log_r(lag_alpha) : lag;
+          const R delta = -dU / kT + log_r(st1 / st0) + dw + log_r(alpha) - lg;
+          const R eps = u01<R>(weps);
+          return (delta >= 0) || (eps < exp_r(delta));
+        });
+      } else {   // f32: the same test with the logarithm folded away, (1 + u) sin0 < sin1 e alpha + sin0 (cf. pstat_cluster.hip)
         const R lg = lag_pending ? log_r(lag_alpha) : lag;
-        const R delta = -dU / kT + log_r(st1 / st0) + dw + log_r(alpha) - lg;
-        const R eps = u01<R>(weps);
-        return (delta >= 0) || (eps < exp_r(delta));
-      });
+        const R e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lg) + dU * nbeta_log2e) * alpha;
+        ok = bits12(weps) * st0 < fma_r(st1, e, st0);
+      }
       ok = ok && !edge;
       if constexpr (EN == PSTAT_ISING) nnan_seg += not_finite(dU) ? 1 : 0;
 
@@ -498,34 +549,34 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
         const uint32_t os = ok ? off0 : OOB;
 #endif
         st(os, n1.x, n1.y);
-        st(os + 16, flipped ? -n1.z : n1.z, flipped ? refl_theta(th1) : th1);
-        if constexpr (CELL == 40) st8(os + 32, ph1); else st(os + 32, ph1, st1);
+        st(os + HB, flipped ? -n1.z : n1.z, flipped ? refl_theta(th1) : th1);
+        st8(os + 2 * HB, ph1);
         if (any_flip) {
           // the members inside the window come out of its registers: n_z -> -n_z, theta reflected
           const int ku = upper - idx, kl = idx - lower;
 #pragma unroll
           for (int k = 1; k <= W; ++k) {
-            st((okf && k <= ku) ? off0 + (uint32_t)k * CELL + 16 : OOB, -ub[k].x, refl_theta(ub[k].y));
-            st((okf && k <= kl) ? off0 - (uint32_t)k * CELL + 16 : OOB, -db[k].x, refl_theta(db[k].y));
+            st((okf && k <= ku) ? off0 + (uint32_t)k * CELL + HB : OOB, -ub[k].x, refl_theta(ub[k].y));
+            st((okf && k <= kl) ? off0 - (uint32_t)k * CELL + HB : OOB, -db[k].x, refl_theta(db[k].y));
           }
           if (__builtin_amdgcn_ballot_w64(okf && (ku > W || kl > W)) != 0) {
 #pragma unroll
             for (int k = W + 1; k <= W + E; ++k) {
-              st((okf && k <= ku) ? off0 + (uint32_t)k * CELL + 16 : OOB, -ub[k].x, refl_theta(ub[k].y));
-              st((okf && k <= kl) ? off0 - (uint32_t)k * CELL + 16 : OOB, -db[k].x, refl_theta(db[k].y));
+              st((okf && k <= ku) ? off0 + (uint32_t)k * CELL + HB : OOB, -ub[k].x, refl_theta(ub[k].y));
+              st((okf && k <= kl) ? off0 - (uint32_t)k * CELL + HB : OOB, -db[k].x, refl_theta(db[k].y));
             }
             // members beyond the requested rows: read-modify-write, four rows of either side per pass
             for (int i = W + E + 1; __builtin_amdgcn_ballot_w64(okf && (i <= ku || i <= kl)) != 0; i += 4) {
-              v2dd v[8];
+              P2 v[8];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                v[j] = ld((okf && i + j <= ku) ? off0 + (uint32_t)(i + j) * CELL + 16 : OOB);
-                v[4 + j] = ld((okf && i + j <= kl) ? off0 - (uint32_t)(i + j) * CELL + 16 : OOB);
+                v[j] = ld((okf && i + j <= ku) ? off0 + (uint32_t)(i + j) * CELL + HB : OOB);
+                v[4 + j] = ld((okf && i + j <= kl) ? off0 - (uint32_t)(i + j) * CELL + HB : OOB);
               }
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                st((okf && i + j <= ku) ? off0 + (uint32_t)(i + j) * CELL + 16 : OOB, -v[j].x, refl_theta(v[j].y));
-                st((okf && i + j <= kl) ? off0 - (uint32_t)(i + j) * CELL + 16 : OOB, -v[4 + j].x, refl_theta(v[4 + j].y));
+                st((okf && i + j <= ku) ? off0 + (uint32_t)(i + j) * CELL + HB : OOB, -v[j].x, refl_theta(v[j].y));
+                st((okf && i + j <= kl) ? off0 - (uint32_t)(i + j) * CELL + HB : OOB, -v[4 + j].x, refl_theta(v[4 + j].y));
               }
             }
           }
@@ -559,7 +610,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
 
     {
       double *const sm_ = S.sums + c;
-      auto add = [&](const int q, const R v) __attribute__((always_inline)) { sm_[(int64_t)q * C] += v; };
+      auto add = [&](const int q, const R v) __attribute__((always_inline)) { sm_[(int64_t)q * C] += (double)v; };
       add(S_R1, a1[0]); add(S_R2, a1[1]); add(S_R3, a1[2]);
       add(S_P1, a1[3]); add(S_P2, a1[4]); add(S_P3, a1[5]);
       add(S_U, a1[6]); add(S_C2, a1[7]); add(S_PSI, a1[8]);
@@ -567,7 +618,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
       add(S_P1SQ, a2[3]); add(S_P2SQ, a2[4]); add(S_P3SQ, a2[5]);
       add(S_USQ, a2[6]);
     }
-    wnorm += accw;
+    wnorm += (double)accw;
     step += chunk;
     left -= chunk;
     steps_seg += chunk;
@@ -588,6 +639,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
           phistep /= A.adj_scale;
           thstep /= A.adj_scale;
         }
+        phs = (R)(phistep / AG::unit); ths = (R)(thstep / AG::unit);
       }
     }
   }
@@ -604,9 +656,8 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
 #pragma unroll 4
     for (int i = 0; i < n; ++i) {
       const uint32_t o = row_off(i);
-      const v2dd b1 = ld(o + 16);
-      v2dd b2;
-      if constexpr (CELL == 40) b2 = v2dd{ld8(o + 32), 0.0}; else b2 = ld(o + 32);
+      const P2 b1 = ld(o + HB);
+      const P2 b2 = P2{ld8(o + 2 * HB), (R)0};
       gth[(int64_t)i * C + c] = b1.y;
       gph[(int64_t)i * C + c] = b2.x;
     }
@@ -624,33 +675,36 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
   if (umb) S.wnorm[c] = wnorm;
 }
 
-template <typename G, int CT, int EN>
+template <typename R, typename G, int CT, int EN>
 __global__ __launch_bounds__(64) void cluster_gm_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
                                                         int umbrella, int *__restrict__ queue) {
   const int lane = threadIdx.x;
   run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len, int blk) {
-    run_cluster_segment_gm<G, CT, EN>(A, S, cc, umbrella, lane, chain, first, len, blk);
+    run_cluster_segment_gm<R, G, CT, EN>(A, S, cc, umbrella, lane, chain, first, len, blk);
   }, cases);
 }
 
 using ClusterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int *);
 
-template <typename G>
+template <typename R, typename G>
 ClusterFn pick_ct_en(const LaunchCfg &cfg) {
   const bool ising = cfg.energy_type == PSTAT_ISING;
   if (cfg.chain_type == PSTAT_DIELECTRIC)
-    return ising ? cluster_gm_kernel<G, PSTAT_DIELECTRIC, PSTAT_ISING> : cluster_gm_kernel<G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING>;
-  return ising ? cluster_gm_kernel<G, PSTAT_POLAR, PSTAT_ISING> : cluster_gm_kernel<G, PSTAT_POLAR, PSTAT_NONINTERACTING>;
+    return ising ? cluster_gm_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_ISING> : cluster_gm_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING>;
+  return ising ? cluster_gm_kernel<R, G, PSTAT_POLAR, PSTAT_ISING> : cluster_gm_kernel<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING>;
 }
 
 ClusterFn pick(const LaunchCfg &cfg) {
-  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_ct_en<Xoshiro128pp>(cfg) : pick_ct_en<Mwc64x>(cfg);
+  const bool xo = cfg.rng == PSTAT_RNG_XOSHIRO128PP;
+  if (cfg.precision == PSTAT_F64) return xo ? pick_ct_en<double, Xoshiro128pp>(cfg) : pick_ct_en<double, Mwc64x>(cfg);
+  return xo ? pick_ct_en<float, Xoshiro128pp>(cfg) : pick_ct_en<float, Mwc64x>(cfg);
 }
 
 }  // namespace
 
-size_t cluster_gm_work_bytes(const SweepArgs &a) {
-  return (size_t)(a.blocks_per_case * a.ncases) * (size_t)a.lanes * (size_t)a.n * CELL;
+size_t cluster_gm_work_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
+  return (size_t)(a.blocks_per_case * a.ncases) * (size_t)a.lanes * (size_t)a.n *
+         (cfg.precision == PSTAT_F64 ? cell_bytes<double>() : cell_bytes<float>());
 }
 
 hipError_t cluster_gm_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes, int *blocks_per_cu,
@@ -661,7 +715,7 @@ hipError_t cluster_gm_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int 
   if (e != hipSuccess) return e;
   if (lds_bytes) *lds_bytes = 0;
   if (blocks_per_cu) *blocks_per_cu = nb;
-  if (name) *name = "cluster_kernel<double, state in memory>";
+  if (name) *name = cfg.precision == PSTAT_F64 ? "cluster_kernel<double, state in memory>" : "cluster_kernel<float, state in memory>";
   return hipSuccess;
 }
 

@@ -39,8 +39,8 @@ struct DevState {
                         //                in value/normalizer, inc/average.jl:38,63-67)
   void *work;           // f64 "state in memory" kernels only: the waves' working copy of their chains while a segment
                         //                runs (filled from / spilled to `ang` like LDS is); not checkpointed.  Sweep:
-                        //                [chain block][n][64] double2 (theta, phi).  Clustering main: [chain block][lane][n]
-                        //                48-byte cells (pstat_cluster_gm.hip)
+                        //                [chain block][n][64] double2 (theta, phi), chain-contiguous for the Ising energy.
+                        //                Clustering main: [chain block][lane][n] 40-byte (f32: 20-byte) cells (pstat_cluster_gm.hip)
   int64_t *nanrej;      // i64[C]         proposals whose trial energy was NaN or +-Inf (1/r^3 singularities of the
                         //                pair energies; the reference rejects them silently, inc/acceptance.jl:29-39)
   int64_t C;
@@ -266,12 +266,12 @@ hipError_t launch_cluster(const LaunchCfg &cfg, const SweepArgs &a, const DevSta
                           const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream);
 hipError_t cluster_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
                                int *blocks_per_cu, const char **name);
-// the f64 cluster kernel with its chains in DevState::work (pstat_cluster_gm.hip); chosen by f64_state_global()
+// the cluster kernel with its chains in DevState::work (pstat_cluster_gm.hip: f64, and f32 for large ensembles); chosen by f64_state_global()
 hipError_t launch_cluster_gm(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                              const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream);
 hipError_t cluster_gm_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
                                   int *blocks_per_cu, const char **name);
-size_t cluster_gm_work_bytes(const SweepArgs &a);
+size_t cluster_gm_work_bytes(const LaunchCfg &cfg, const SweepArgs &a);
 hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                         const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream);
 size_t sweep_queue_ints(const SweepArgs &a);
@@ -288,7 +288,7 @@ size_t reduce_scratch_doubles();
 hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_bytes,
                              int *blocks_per_cu, const char **name);
 int choose_lanes(int precision, int64_t n, int energy_type);
-bool f64_state_global(const LaunchCfg &cfg, int64_t n);   // the f64 chain-per-lane kernel of this configuration keeps its state in DevState::work
+bool f64_state_global(const LaunchCfg &cfg, int64_t n, int64_t total_chains);   // the f64 chain-per-lane kernel of this configuration keeps its state in DevState::work
 // --energy-type interacting: one chain per wavefront (pstat_interacting.hip), n <= 256
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                               const CaseConst *cases, int reinit_mode, hipStream_t stream);

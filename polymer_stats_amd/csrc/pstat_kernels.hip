@@ -1042,8 +1042,21 @@ SweepFn pick_sweep_f64g(const LaunchCfg &cfg);
 // (n > 40) the non-interacting f64 sweep keeps its cells in global memory instead and runs 64 lanes on every
 // SIMD (run_segment, ST = 2).  PSTAT_F64_STATE=lds|global overrides the choice (experiments, tests).
 // The clustering main's chain-per-lane kernel always keeps its chains in memory (pstat_cluster_gm.hip).
-bool f64_state_global(const LaunchCfg &cfg, int64_t n) {
-  if (cfg.precision != PSTAT_F64 || (cfg.energy_type != PSTAT_NONINTERACTING && cfg.energy_type != PSTAT_ISING)) return false;
+bool f64_state_global(const LaunchCfg &cfg, int64_t n, int64_t total_chains) {
+  if (cfg.energy_type != PSTAT_NONINTERACTING && cfg.energy_type != PSTAT_ISING) return false;
+  if (cfg.precision == PSTAT_F32 && cfg.move_set == PSTAT_MOVES_CLUSTER) {
+    // The f32 clustering main has the in-memory kernel too (20-byte cells, pstat_cluster_gm.hip).  Its LDS kernel is the
+    // faster one while the ensemble is resident or nearly so (measured, 65 536 chains: n <= 80 2.2-2.5e10 proposals/s
+    // against 1.8-2.4e10; n = 100 a tie; the 546 x 64-chain n = 200 phase scan 1.88 s against 2.18 s); an ensemble of more
+    // than twice what LDS seats (160 KiB / 8 n chains per CU) runs in memory (n = 200, 65 536 chains: 1.5e10 against 7.7e9).
+    // PSTAT_F32_STATE=lds|global overrides (tests).
+    const char *e = getenv("PSTAT_F32_STATE");
+    if (e && e[0] == 'l') return false;
+    if (e && e[0] == 'g') return true;
+    const int64_t seats = (160 * 1024 / (8 * (n > 0 ? n : 1))) * 256;
+    return total_chains > 2 * seats;
+  }
+  if (cfg.precision != PSTAT_F64) return false;
   const char *e = getenv("PSTAT_F64_STATE");
   if (e && e[0] == 'l') return false;
   if (e && e[0] == 'g') return true;

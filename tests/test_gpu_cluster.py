@@ -231,13 +231,22 @@ def test_f32_all_pairs_cluster_statistics(ps, oracle):
     assert np.all(np.abs(z) < 4.5), (z, gm, om)
 
 
+@pytest.fixture(params=["lds", "memory"])
+def f32_home(request, monkeypatch):
+    """The f32 chain-per-lane cluster kernel has both homes too: cells in LDS (the default while the ensemble is at most
+    twice what LDS seats) or 20-byte cells with cached n-hat in device memory (pstat_cluster_gm.hip, beyond)."""
+    monkeypatch.setenv("PSTAT_F32_STATE", "global" if request.param == "memory" else "lds")
+    return request.param
+
+
 @pytest.mark.parametrize("energy_type,K1", [(0, 1.0), (2, 0.2)])
-def test_f32_cluster_statistics(ps, oracle, energy_type, K1):
+def test_f32_cluster_statistics(ps, oracle, energy_type, K1, f32_home):
     kw = dict(n=20, E0=1.0, K1=K1, K2=0.1 * K1, Fz=0.8, kT=1.0, seed=31, bend_mod=0.5, bend_angle=0.3,
               cluster_prob=0.5, energy_type=energy_type)
     nsteps, burn = 20000, 3000
     op, pp = _pair(ps, nsteps, 4096, ps.F32, (1.0,), burn, **kw)
     with ps.Ensemble(pp) as e:
+        assert ("state in memory" in e.launch_info().kernel.decode()) == (f32_home == "memory")
         _run_gpu(e, pp, nsteps, (1.0,), burn)
         s = e.summary()
     gm, gs = np.array(s.avg), np.array(s.stderr)
@@ -507,3 +516,26 @@ def test_f64_cluster_in_memory_time_segments(ps, monkeypatch):
             assert a["nacc_total"] == b["nacc_total"] and a["phi_step"] == b["phi_step"]
             np.testing.assert_allclose(a["sums"], b["sums"], rtol=1e-10, atol=1e-8)
         np.testing.assert_allclose(states["1"][-1], states[nseg][-1], rtol=1e-10, atol=1e-8)
+
+
+def test_f32_cluster_homes_agree_at_scale_and_default_home(ps, monkeypatch):
+    """f32 clustering main: the LDS kernel and the in-memory one are independent samples of one algorithm -- every pooled
+    average within 4.5 combined standard errors at n = 120, long runs included (the f32 running totals are re-derived at every segment start in both)."""
+    out = {}
+    kw = dict(n=120, E0=1.0, K1=0.0, K2=1.0, kT=1.0, adj_ub=0.40, Fz=0.3, Fx=0.2, bend_mod=0.3)
+    for where in ("lds", "global"):
+        monkeypatch.setenv("PSTAT_F32_STATE", where)
+        pp = ps.default_params(num_chains=16384, precision=ps.F32, seed=201 + len(out), move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, **kw)
+        with ps.Ensemble(pp) as e:
+            assert ("state in memory" in e.launch_info().kernel.decode()) == (where == "global")
+            _run_gpu(e, pp, 40000, (10.0, 1.0), 4000)
+            s = e.summary()
+            out[where] = (np.r_[s.avg, s.extra_avg, s.acceptance_ratio], np.r_[s.stderr, s.extra_stderr, s.ar_stderr])
+            # the reported microstate is the microstate of the stored angles (no drift of the f32 totals)
+    z = (out["global"][0] - out["lds"][0]) / np.sqrt(out["global"][1] ** 2 + out["lds"][1] ** 2 + 1e-300)
+    assert np.all(np.abs(z) < 4.5), (z, out["global"][0], out["lds"][0])
+    monkeypatch.delenv("PSTAT_F32_STATE")
+    # default home: LDS while the ensemble is at most twice what LDS seats (160 KiB / 8 n chains per CU), memory beyond
+    for n, chains, mem in ((200, 64, False), (200, 32768, False), (200, 65536, True), (100, 65536, False), (20, 131072, False)):
+        with ps.Ensemble(ps.default_params(num_chains=chains, precision=ps.F32, n=n, move_set=ps.MOVES_CLUSTER)) as e:
+            assert ("state in memory" in e.launch_info().kernel.decode()) == mem, (n, chains)
