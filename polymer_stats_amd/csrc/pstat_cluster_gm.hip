@@ -675,8 +675,14 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
   if (umb) S.wnorm[c] = wnorm;
 }
 
+#ifndef PSTAT_GM_WAVES
+#define PSTAT_GM_WAVES 1   // waves per SIMD the register allocator is asked for: f64 needs the whole file (at 2: ~250 spilled registers)
+#endif
+#ifndef PSTAT_GM_WAVES_F32
+#define PSTAT_GM_WAVES_F32 2   // f32 fits 256 registers with ~20 spilled ones: a second wave per SIMD hides latency for ensembles >= 131 072 chains (+10...19 %)
+#endif
 template <typename R, typename G, int CT, int EN>
-__global__ __launch_bounds__(64) void cluster_gm_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
+__global__ __launch_bounds__(64, sizeof(R) == 4 ? PSTAT_GM_WAVES_F32 : PSTAT_GM_WAVES) void cluster_gm_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
                                                         int umbrella, int *__restrict__ queue) {
   const int lane = threadIdx.x;
   run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len, int blk) {
