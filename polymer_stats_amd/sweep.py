@@ -86,13 +86,16 @@ def julia_range(text: str) -> list:
 
 
 def axis_values(text: str) -> list:
-    """`1,5,10` | `0:0.2:5` | `10^(-2:0.2:2)` (run/K1_E0-kT-phase.jl:22-27) -> values."""
+    """`1,5,10` | `0:0.2:5` | `10^(-2:0.2:2)` (run/K1_E0-kT-phase.jl:22-27) | `0:0.05:1,1.5:0.5:5` (vcat of ranges,
+    run/noninteracting-compare-with-clustering_2021-09-24.jl:21) -> values."""
     t = text.strip()
     if t.startswith("10^(") and t.endswith(")"):
         return [float(10.0 ** x) for x in julia_range(t[4:-1])]
-    if "," in t or ":" not in t:
-        return [_number(x) for x in t.split(",") if x.strip()]
-    return julia_range(t)
+    out = []
+    for item in t.split(","):
+        if item.strip():
+            out += julia_range(item) if ":" in item else [_number(item)]
+    return out
 
 
 def product_cases(axes: list[tuple[str, list]]) -> list[dict]:

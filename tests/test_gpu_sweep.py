@@ -127,10 +127,12 @@ def test_cli_with_two_ranks_and_the_aggregate_reaches_the_closed_form(tmp_path, 
     assert list(col["Fz"]) == [0.0, 1.0, 5.0] and set(col["n"]) == {100.0}
     for i, key in enumerate(["cfg2_n100_E0_1_K1_1_Fz0", "cfg2_n100_E0_1_K1_1_Fz1", "cfg2_n100_E0_1_K1_1_Fz5"]):
         g = golden[key]["avg"]
-        # 1 024 chains x 20 000 steps: the standard error of <r_z> is ~0.02, of <U> ~0.03 (tests/test_gpu_validation.py runs
-        # the same configuration at 5 sigma with measured errors); here 0.15 absolute / 0.5 % relative
-        for name, gk in (("r3", "r3"), ("p3", "p3"), ("U", "U"), ("r1sq", "r1sq"), ("rsquared", "rsq"), ("Usquared", "Usq"), ("psquared", "psq")):
-            assert col[name][i] == pytest.approx(g[gk], rel=5e-3, abs=0.15), (key, name, col[name][i], g[gk])
+        # 1 024 chains x 20 000 steps, ~200 steps of autocorrelation: standard errors ~0.02 on <r_z>, ~0.13 on <r_x^2> (variance
+        # 2 <r_x^2>^2), ~0.03 on <U>; bounds at >= 5 of those (tests/test_gpu_validation.py runs the same configuration at
+        # 5 sigma with MEASURED errors -- this test is about the files)
+        for name, gk, rel, ab in (("r3", "r3", 0, 0.15), ("p3", "p3", 0, 0.15), ("U", "U", 5e-3, 0.2), ("r1sq", "r1sq", 0, 0.8),
+                                  ("rsquared", "rsq", 1e-2, 1.0), ("Usquared", "Usq", 1e-2, 1.0), ("psquared", "psq", 1e-2, 1.0)):
+            assert col[name][i] == pytest.approx(g[gk], rel=rel or None, abs=ab), (key, name, col[name][i], g[gk])
         assert col["lambda3"][i] == pytest.approx(col["r3"][i] / 100.0, rel=1e-12, abs=1e-15)
     # again: everything is there, nothing runs
     r = subprocess.run(cmd[:cmd.index("--aggregate")] + cmd[cmd.index("--"):], capture_output=True, text=True, timeout=300)

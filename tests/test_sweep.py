@@ -17,6 +17,8 @@ def test_axes_follow_the_reference_grids():
     assert sw.axis_values("1:25") == list(range(1, 26)) and all(isinstance(v, int) for v in sw.axis_values("1:25"))
     assert sw.axis_values("0.1,1,10") == [0.1, 1, 10] and sw.axis_values("100") == [100]
     assert sw.axis_values("0:0.05:1")[-1] == 1.0 and len(sw.axis_values("0:0.05:1")) == 21   # run/noninteracting-compare...:21
+    Fzs = sw.axis_values("0.0:0.05:1.0,1.5:0.5:5.0")                  # vcat(0.0:0.05:1.0, 1.5:0.5:5.0)
+    assert len(Fzs) == 21 + 8 and Fzs[20] == 1.0 and Fzs[21] == 1.5 and Fzs[-1] == 5.0
     with pytest.raises(ValueError):
         sw.axis_values("1:0:5")
     with pytest.raises((ValueError, SyntaxError)):

@@ -36,7 +36,7 @@ def main():
     ap.add_argument("workdir")
     ap.add_argument("--main", choices=["mcmc_eap_chain", "mcmc_clustering_eap_chain"], default="mcmc_eap_chain")
     ap.add_argument("--axis", action="append", default=[], metavar="KEY=VALUES",
-                    help="values: a,b,c | start:step:stop | 10^(start:step:stop); first axis = outermost loop")
+                    help="values: a,b,c | start:step:stop (also several, comma-separated) | 10^(start:step:stop); first axis = outermost loop")
     ap.add_argument("--cases", default="", help="JSON array of case objects instead of (or appended to) the axes' product")
     ap.add_argument("--skip", default="", help="leave out the cases for which this holds, e.g. 'K1==K2'")
     ap.add_argument("--name", default="", help="file-name tokens, e.g. E0,K1,K2,kT,Fz,Fx,n,b,run:int (kinds: milli [default] | int | raw)")
