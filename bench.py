@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 FZ_SWEEP = [round(0.05 * i, 2) for i in range(21)] + [1.5 + 0.5 * i for i in range(8)]  # run/noninteracting-compare-*.jl:21
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz = 7.86e13 f32 lane-ops/s (f64: half of it)
+NUM_SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 LDS_PEAK_GBS = 256 * 256 * 2.4              # CUs x 256 B/clk (MI355X_MICROARCH.md, LDS) x GHz = 157 TB/s
 VALU_OPS_ESTIMATE = {"f32": 85, "f64": 257, "q16": 85}   # last PMC counts (profiles/r02); replaced by the stamped record when valid
 VALU_F64_OPS_ESTIMATE = {"f64": 128.0}                   # of which f64 ops; likewise replaced
@@ -299,6 +300,10 @@ def main():
         other_ops = max(0.0, valu_ops - f64_ops)
         issue_frac = rate * (f64_ops / (0.5 * VALU_LANE_OPS_PEAK) + other_ops / VALU_LANE_OPS_PEAK)
         last, info = rec["last"], rec["info"]
+        # what ONE wave per SIMD can issue: a vector instruction every 4 cycles whatever its type (MI355X_MICROARCH.md, row
+        # 'vector-instruction ISSUE cost'); the 2-cycle rate of 32-bit ops needs a second wave on the SIMD to fill the other slot
+        waves_per_simd = info.blocks * ((info.lanes_per_block + 63) // 64) / float(NUM_SIMDS)
+        one_wave_frac = rate * valu_ops * 4.0 / 64.0 / (NUM_SIMDS * CLOCK_HZ) if waves_per_simd <= 1.0 else None
         in_memory = "state in L2" in info.kernel.decode()
         # state in memory: (LDS bytes / 1 KiB per row of 64 lanes x 16 B) - 1 trash row = monomers whose cells are in LDS
         lds_share = min(1.0, (info.lds_bytes // 1024 - 1) / args.n) if in_memory else 1.0
@@ -325,6 +330,11 @@ def main():
                      "unit": "T lane-ops/s", "frac": issue_frac,
                      "ops_per_update": valu_ops, "f64_ops_per_update": f64_ops, "other_ops_per_update": other_ops,
                      "frac_note": "issue time: f64 ops priced at 16 lanes/clk/SIMD (3.93e13 lane-ops/s), all others at 32 (7.86e13)",
+                     "waves_per_simd": waves_per_simd, "frac_one_wave_issue": one_wave_frac,
+                     "frac_one_wave_issue_note": "this launch seats at most one wave per SIMD, and one wave issues one vector "
+                                                 "instruction per 4 cycles whatever its type: ops_per_update x 4 cycles x wave-steps/s "
+                                                 "/ (1024 SIMDs x 2.4 GHz) -- the ceiling that applies to this ensemble size "
+                                                 "(the chip holds ~1.9 GHz under this load, DESIGN 3.9)",
                      "ops_source": src},
             "lds": {"bound": "lds-bandwidth", "achieved": lds_share * STATE_BYTES[precision] * rate / 1e9, "peak": LDS_PEAK_GBS,
                     "unit": "GB/s", "frac": lds_share * STATE_BYTES[precision] * rate / 1e9 / LDS_PEAK_GBS,
