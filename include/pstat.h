@@ -71,7 +71,7 @@ enum { PSTAT_RNG_MWC64X = 0, PSTAT_RNG_XOSHIRO128PP = 1 };
  *   PSTAT_MOVES_CLUSTER  mcmc_clustering_eap_chain.jl:268-279 -- the same move followed, on the trial
  *                        chain, by cluster_flip! (inc/eap_chain.jl:269-333); bending energy; two more
  *                        averagers (sum cos^2 theta, mean bond angle).  All four energies; the all-pairs
- *                        ones (interacting, cutoff) run one chain per wavefront, n <= 512 (the fixed-force main: n <= 256). */
+ *                        ones (interacting, cutoff) run one chain per wavefront, n <= 512. */
 enum { PSTAT_MOVES_SINGLE = 0, PSTAT_MOVES_CLUSTER = 1 };
 
 /* Flattened pargs::Dict (mcmc_eap_chain.jl:155) -- the keys the force-ensemble step loop reads. */

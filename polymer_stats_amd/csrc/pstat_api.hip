@@ -94,12 +94,9 @@ int validate(const pstat_params *c, int ncases) {
   if (b.energy_type == PSTAT_CUTOFF && b.move_set != PSTAT_MOVES_CLUSTER)
     return fail(PSTAT_ERR_INVALID_ARG, "energy-type 'cutoff' belongs to the clustering main (mcmc_eap_chain.jl has "
                 "no --cutoff-radius)");
-  if (all_pairs(b.energy_type) && b.move_set == PSTAT_MOVES_CLUSTER && b.n <= 512) {
-    // the clustering main's all-pairs kernel carries up to 8 monomers per lane (f64: a few dozen registers spill there)
-  } else if (all_pairs(b.energy_type) && b.n > 256)
-    return fail(PSTAT_ERR_UNSUPPORTED, "the all-pairs energies run one chain per 64-lane wavefront with up to 4 "
-                "monomers per lane (8 for the clustering main): num-monomers must be <= 256 (512), got %lld",
-                (long long)b.n);
+  if (all_pairs(b.energy_type) && b.n > 512)
+    return fail(PSTAT_ERR_UNSUPPORTED, "the all-pairs energies run one chain per 64-lane wavefront with up to 8 "
+                "monomers per lane: num-monomers must be <= 512, got %lld", (long long)b.n);
   if (b.precision != PSTAT_F32 && b.precision != PSTAT_F64 && b.precision != PSTAT_Q16)
     return fail(PSTAT_ERR_INVALID_ARG, "precision must be PSTAT_F32, PSTAT_F64 or PSTAT_Q16");
   if (b.precision == PSTAT_Q16 && all_pairs(b.energy_type))

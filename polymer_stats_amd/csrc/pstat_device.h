@@ -289,7 +289,7 @@ hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_
                              int *blocks_per_cu, const char **name);
 int choose_lanes(int precision, int64_t n, int energy_type);
 bool f64_state_global(const LaunchCfg &cfg, int64_t n, int64_t total_chains);   // the f64 chain-per-lane kernel of this configuration keeps its state in DevState::work
-// --energy-type interacting: one chain per wavefront (pstat_interacting.hip), n <= 256
+// --energy-type interacting: one chain per wavefront (pstat_interacting.hip), n <= 512
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                               const CaseConst *cases, int reinit_mode, hipStream_t stream);
 // clustering main with the all-pairs energies (interacting, cutoff): pstat_cluster_wave.hip

@@ -1,7 +1,7 @@
 // pstat_interacting.hip -- gfx950 kernel for --energy-type interacting (inc/energy.jl:11-16,
 // U_interaction inc/eap_chain.jl:196-211): every trial move needs the O(n^2) dipole-dipole sum.
 //
-// Mapping: ONE CHAIN PER WAVEFRONT, lane l owns M = 1, 2 or 4 consecutive monomers (n <= 64 M = 256; the
+// Mapping: ONE CHAIN PER WAVEFRONT, lane l owns M = 1, 2, 4 or 8 consecutive monomers (n <= 64 M = 512; the
 // reference's own interacting sweeps use n = 100 and 200, run/interacting_dielectric_study.jl:26).  Per lane in registers: the
 // angles, n-hat, dipole and position of its monomer.  Everything that is one-per-chain (generator,
 // proposal, r, p, U, running sums) is wave-uniform: the generator lives in SGPRs and runs on the
@@ -54,10 +54,14 @@ template <typename R, typename G, int CT, int M>
 #define PSTAT_IOCC_F64M4 1   // (measured round 2 with the rsq-Newton term: F64M2 / F64M4 = 2/1 1.34e8 | 3.38e7 at n = 100 | 200;
                              //  2/2 1.34e8 | 3.23e7; 3/1 1.20e8 | 3.38e7: the round-1 choice stands)
 #endif
+#ifndef PSTAT_IOCC_M8
+#define PSTAT_IOCC_M8 1      // 257 <= n <= 512 (eight monomers per lane: f64 spills a few dozen registers there, like the
+#endif                       //  clustering main's all-pairs kernel at that size)
 #ifndef PSTAT_IOCC_F64M1
 #define PSTAT_IOCC_F64M1 3   // (measured round 2, n = 64: 2 waves 3.47e8, 3 waves see DESIGN, 4 waves 2.68e8 -- spills)
 #endif
-__global__ __launch_bounds__(64, sizeof(R) == 8 ? (M == 1 ? PSTAT_IOCC_F64M1 : (M == 2 ? PSTAT_IOCC_F64M2 : PSTAT_IOCC_F64M4))
+__global__ __launch_bounds__(64, M == 8 ? PSTAT_IOCC_M8 :
+                                 sizeof(R) == 8 ? (M == 1 ? PSTAT_IOCC_F64M1 : (M == 2 ? PSTAT_IOCC_F64M2 : PSTAT_IOCC_F64M4))
                                                 : (M == 1 ? PSTAT_IOCC_M1 : (M == 2 ? PSTAT_IOCC_M2 : PSTAT_IOCC_M4))) void interacting_kernel(SweepArgs A, DevState S,
                                                          const CaseConst *__restrict__ cases,
                                                          int do_flips, int use_lag, int umb,
@@ -375,7 +379,8 @@ static InterFn pick_interacting_m(const LaunchCfg &cfg, int64_t n) {
   const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
   if (n <= 64) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 1> : interacting_kernel<R, G, PSTAT_POLAR, 1>;
   if (n <= 128) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 2> : interacting_kernel<R, G, PSTAT_POLAR, 2>;
-  return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 4> : interacting_kernel<R, G, PSTAT_POLAR, 4>;
+  if (n <= 256) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 4> : interacting_kernel<R, G, PSTAT_POLAR, 4>;
+  return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 8> : interacting_kernel<R, G, PSTAT_POLAR, 8>;
 }
 
 // Two objects are built from this file (csrc/Makefile): -DPSTAT_IPART=1 holds the f32 instantiations, compiled

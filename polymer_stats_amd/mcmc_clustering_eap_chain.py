@@ -10,7 +10,7 @@ note they differ from mcmc_eap_chain.jl: energy-type defaults to Ising, step-adj
 num-steps to 1e6, and there is a 5-rung burn-in ladder by default).  Added: --num-chains, --seed,
 --devices, --precision, --rng.
 
-All four energy types run on the device (interacting and cutoff: one chain per wavefront, n <= 256),
+All four energy types run on the device (interacting and cutoff: one chain per wavefront, n <= 512),
 and both forms of --x0 ([phi; theta] for every monomer, or 2 n interleaved per-monomer angles).
 """
 from __future__ import annotations

@@ -111,6 +111,18 @@ def test_f64_bit_parity_interacting_long_chains(ps, oracle, n):
                 steps_per_adjust=100)
 
 
+@pytest.mark.parametrize("n,kw", [(300, dict(K2=0.1, Fx=0.1)), (512, dict(chain_type=1, mu=0.6, do_flips=1)), (257, dict(rng=1))],
+                         ids=["n300", "n512-polar-flips", "n257-xoshiro"])
+def test_f64_bit_parity_interacting_eight_monomers_per_lane(ps, oracle, n, kw):
+    """Beyond the reference's own sweeps (n <= 200): 257 <= n <= 512 runs eight monomers per lane in the fixed-force main
+    too, bit-identical to the oracle; n = 513 is refused by both mains."""
+    _bit_parity(ps, oracle, 160, 2, n=n, E0=1.0, K1=1.0, Fz=0.5, energy_type=1, seed=29, steps_per_adjust=50, **kw)
+    for move_set in (ps.MOVES_SINGLE, ps.MOVES_CLUSTER):
+        with pytest.raises(ps.PstatError) as ei:
+            ps.Ensemble(ps.default_params(n=513, energy_type=1, move_set=move_set))
+        assert ei.value.code == -4 and "512" in str(ei.value)
+
+
 def test_f64_interacting_umbrella_and_reinit(ps, oracle):
     """The remaining options of the in-scope main on the interacting kernel: --umbrella-sampling and
     --num-inits (forced and Metropolis re-initialisation, with the acceptor's stale cache)."""
@@ -391,7 +403,7 @@ def test_errors_are_loud(ps):
     with pytest.raises(ps.PstatError):
         ps.Ensemble(ps.default_params(kT=0.0))
     with pytest.raises(ps.PstatError) as ei:
-        ps.Ensemble(ps.default_params(energy_type=ps.INTERACTING, n=300))   # > 4 monomers per lane
+        ps.Ensemble(ps.default_params(energy_type=ps.INTERACTING, n=600))   # > 8 monomers per lane
     assert ei.value.code == -4
 
 

@@ -89,9 +89,9 @@ def test_reference_validation_sweep_against_langevin(ps, prec):
             assert s.avg[7] == 0.0 and s.avg[9] == 0.0                           # E0 = 0: no dipoles
 
 
-@pytest.mark.parametrize("n,nsteps", [(64, 1500), (100, 1000), (200, 500)], ids=["n64-M1", "n100-M2", "n200-M4"])
+@pytest.mark.parametrize("n,nsteps", [(64, 1500), (100, 1000), (200, 500), (300, 250)], ids=["n64-M1", "n100-M2", "n200-M4", "n300-M8"])
 def test_f32_all_pairs_kernels_against_oracle_and_f64(ps, oracle, n, nsteps):
-    """interacting_kernel<float, M = 1 | 2 | 4>: M >= 2 runs the packed ring sum (ring_pair_sum_pk), a different
+    """interacting_kernel<float, M = 1 | 2 | 4 | 8>: M >= 2 runs the packed ring sum (ring_pair_sum_pk), a different
     LDS layout and code path from M = 1 and from the f64 template.  (i) a zero-step launch: the initial pair
     energy of the same angles agrees with the f64 kernel's to f32 rounding; (ii) a short pre-collapse run:
     pooled means within 4.5 sigma of the oracle's literal O(n^2) mode; (iii) same seeds, f32 vs f64."""

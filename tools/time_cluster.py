@@ -1,6 +1,6 @@
 """Wall-clock rate of the clustering main's chain-per-lane kernel on the configuration of tools/profile_cluster.py
 (kernel experiments; the driver-facing numbers come from tools/measure_configs.py and bench.py):
-    python tools/time_cluster.py [ni|ising] [f64|f32] [steps=5000] [n=100] [chains=65536]"""
+    python tools/time_cluster.py [ni|ising] [f64|f32] [steps=5000] [n=100] [chains=65536]      (env: CPROB, E0, K1, K2, KT)"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ prec = {"f32": ps.F32, "f64": ps.F64}[sys.argv[2] if len(sys.argv) > 2 else "f64
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 chains = int(sys.argv[5]) if len(sys.argv) > 5 else 65536
-p = ps.default_params(n=n, E0=1.0, K1=0.0, K2=1.0, kT=1.0, energy_type=et, num_chains=chains, precision=prec, seed=6,
+p = ps.default_params(n=n, E0=float(os.environ.get("E0", "1.0")), K1=float(os.environ.get("K1", "0.0")), K2=float(os.environ.get("K2", "1.0")), kT=float(os.environ.get("KT", "1.0")), energy_type=et, num_chains=chains, precision=prec, seed=6,
                       move_set=ps.MOVES_CLUSTER, cluster_prob=float(os.environ.get("CPROB", "0.5")), adj_ub=0.40)
 with ps.Ensemble(p) as e:
     e.advance(steps); e.sync()
