@@ -137,3 +137,41 @@ def test_cli_with_two_ranks_and_the_aggregate_reaches_the_closed_form(tmp_path, 
     # again: everything is there, nothing runs
     r = subprocess.run(cmd[:cmd.index("--aggregate")] + cmd[cmd.index("--"):], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "0 cases run" in r.stderr and "3 already there" in r.stderr
+
+
+def test_cli_explicit_case_list_one_chain_per_case_and_options(tmp_path):
+    """An explicit case list (run/Ising_2025-12-18.jl spells its 23 cases out), ONE chain per case -- literally the reference's
+    sweep --, the fast path and the named generator, CSV files on, then --overwrite; through the command line, one rank."""
+    import json
+    cases = [dict(E0=1, K2=1, K1=0.0, kT=1, Fz=0, Fx=0, n=30, b=1, run=r) for r in (1, 2)] + \
+            [dict(E0=5, K2=0.1, K1=0.0, kT=0.1, Fz=1, Fx=0, n=30, b=0.5, run=1), dict(E0=1, K2=1, K1=0.0, kT=1, Fz=0, Fx=1, n=12, b=2.0, run=1)]
+    spec = tmp_path / "cases.json"
+    spec.write_text(json.dumps(cases))
+    work = tmp_path / "w"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "run_sweep.py"), str(work), "--main", "mcmc_clustering_eap_chain", "--cases", str(spec),
+           "--num-chains", "1", "--seed", "21", "--precision", "f32", "--rng", "xoshiro128++", "--csv",
+           "--", "--chain-type", "dielectric", "--energy-type", "Ising", "--bend-mod", "0.0", "--num-steps", "3000", "--burn-in", "500",
+           "-v", "2", "--stepout", "1000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "4 cases run in 2 ensembles" in r.stderr and "cluster_kernel<float>" in r.stderr
+    names = sorted(f for f in os.listdir(work) if f.endswith(".out"))
+    assert names == sorted(["E0-0001000_K1-0000000_K2-0001000_kT-0001000_Fz-0000000_Fx-0000000_n-0030000_b-0001000_run-001.out",
+                            "E0-0001000_K1-0000000_K2-0001000_kT-0001000_Fz-0000000_Fx-0000000_n-0030000_b-0001000_run-002.out",
+                            "E0-0005000_K1-0000000_K2-0000100_kT-0000100_Fz-0001000_Fx-0000000_n-0030000_b-0000500_run-001.out",
+                            "E0-0001000_K1-0000000_K2-0001000_kT-0001000_Fz-0000000_Fx-0001000_n-0012000_b-0002000_run-001.out"])
+    first = {f: (work / f).read_text() for f in names}
+    assert first[names[0]] != first[names[1]] or "run-001" not in names[0]            # two runs of one case: different seeds
+    assert first[sorted(names)[0]].count("\n") == 12
+    for f in names:
+        roll = (work / f.replace(".out", "_rolling.csv")).read_text().splitlines()
+        assert [x.split(",")[0] for x in roll[1:]] == ["1000.0", "2000.0", "3000.0"] and roll[0].endswith("Ealign,psi")
+        assert len((work / f.replace(".out", "_trajectory.csv")).read_text().splitlines()) == 4
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and "0 cases run" in r2.stderr
+    r3 = subprocess.run(cmd[:3] + ["--overwrite"] + cmd[3:], capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0 and "4 cases run" in r3.stderr
+    assert {f: (work / f).read_text() for f in names} == first                       # same seed, same files
+    # an option the main does not have is the main's own parser error, before anything runs
+    bad = subprocess.run(cmd[:-2] + ["--no-such-option", "1"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "no-such-option" in bad.stderr
