@@ -26,7 +26,7 @@ import numpy as np
 
 from . import _lib
 from .julia_fmt import jl_float, jl_row, jl_vector
-from .mcmc_eap_chain import Averager, ReferenceError_, _Pool, _log, get_avg, resolve_seed
+from .mcmc_eap_chain import Averager, ReferenceError_, _Pool, _averagers, _log, get_avg, resolve_seed
 
 ROLL_HEADER = "step,r1,r2,r3,r1sq,r2sq,r3sq,rsq,p1,p2,p3,p1sq,p2sq,p3sq,psq,U,Usq,Ealign,psi"   # :259
 
@@ -180,24 +180,25 @@ def _dipoles(pargs, phi, theta) -> np.ndarray:
     return pargs["mu"] * np.stack([nx, ny, nz], axis=1)
 
 
-def _stage(pool, nsteps, pargs, kT, write: bool):
-    """One call of the reference's mcmc(nsteps, pargs, chain) (:172-352).  Every call rewrites the two
-    CSV files, so only the last one's survive; earlier rungs skip the writing."""
-    pool.stage(kT)
-    stepout = int(pargs["stepout"])
-    n = pargs["num-monomers"]
-    outfile = rollfile = None
-    if write:
-        outfile = open(f"{pargs['prefix']}_trajectory.csv", "w")
-        rollfile = open(f"{pargs['prefix']}_rolling.csv", "w")
-        outfile.write(traj_header(n) + "\n")
-        rollfile.write(ROLL_HEADER + "\n")
+def _stage(pool, nsteps, mult, write: bool):
+    """One call of the reference's mcmc(nsteps, pargs, chain) (:172-352) at kT x mult, for every case of the pool.  Every
+    call rewrites the two CSV files, so only the last one's survive; earlier rungs skip the writing."""
+    pool.stage(mult)
+    plist = pool.plist
+    pargs = plist[0]
+    stepout = int(pargs["stepout"]) if write else 0
+    files = []
     try:
+        for p in plist if write else []:
+            outfile, rollfile = open(f"{p['prefix']}_trajectory.csv", "w"), open(f"{p['prefix']}_rolling.csv", "w")
+            files.append((outfile, rollfile))
+            outfile.write(traj_header(p["num-monomers"]) + "\n")
+            rollfile.write(ROLL_HEADER + "\n")
         start = last_update = time.time()
         step = 0
         while step < nsteps:
             seg = nsteps - step
-            if write and stepout > 0:
+            if stepout > 0:
                 seg = min(seg, stepout - step % stepout)
             pool.advance(seg)
             step += seg
@@ -205,53 +206,65 @@ def _stage(pool, nsteps, pargs, kT, write: bool):
                 _log(pargs, 3, "Info", f"elapsed: {time.time() - start}")
                 _log(pargs, 3, "Info", f"step:    {step} / {nsteps}")
                 last_update = time.time()
-            if write and stepout > 0 and step % stepout == 0:           # :312-335
-                micro = pool.microstate()
-                st = pool.chain0()
-                mus = _dipoles(pargs, st["phi"], st["theta"])
-                angles = np.stack([st["phi"], st["theta"]], axis=1).reshape(-1)
-                s = pool.summary()
-                outfile.write(jl_row([step, *micro, *angles, *mus.reshape(-1)]) + "\n")
-                rollfile.write(jl_row([step, *s.avg, *s.extra_avg]) + "\n")
-        s = pool.summary()
+            if stepout > 0 and step % stepout == 0:                     # :312-335
+                for k, (outfile, rollfile) in enumerate(files):
+                    micro = pool.microstate(k)
+                    st = pool.chain0(k)
+                    mus = _dipoles(plist[k], st["phi"], st["theta"])
+                    angles = np.stack([st["phi"], st["theta"]], axis=1).reshape(-1)
+                    s = pool.summary(k)
+                    outfile.write(jl_row([step, *micro, *angles, *mus.reshape(-1)]) + "\n")
+                    rollfile.write(jl_row([step, *s.avg, *s.extra_avg]) + "\n")
+        out = [pool.summary(k) for k in range(len(plist))]
         _log(pargs, 3, "Info", f"total time elapsed: {time.time() - start}")
-        _log(pargs, 3, "Info", f"acceptance rate: {s.acceptance_ratio}")
-        return s
+        for k, s in enumerate(out):
+            _log(plist[k], 3, "Info", f"acceptance rate: {s.acceptance_ratio}")
+        return out
     finally:
-        if outfile:
+        for outfile, rollfile in files:
             outfile.close()
             rollfile.close()
 
 
 def run(pargs: dict):
     """The top level of mcmc_clustering_eap_chain.jl:354-387 -> (scalar_averagers, vector_averagers, ar)."""
+    return run_cases([pargs])[0]
+
+
+def run_cases(plist: list, write_csv: bool = True, info: dict | None = None) -> list:
+    """The top level of the clustering main for every case of `plist` at once -- parsed options that differ only in their
+    physics scalars, prefix and seed (one case: the command line; many: a sweep, polymer_stats_amd/sweep.py) -- as ONE
+    ensemble: every rung of the ladder and the recorded run are one launch (per segment) for all of them."""
+    pargs = plist[0]
     if pargs["numeric-type"] not in ("float64", "float128", "dec128", "big"):
         raise ReferenceError_(f"numeric-type '{pargs['numeric-type']}' not understood")    # :191
     try:
         ladder = julia_vector(pargs["burn-schedule"])
     except (ValueError, SyntaxError):
         raise ReferenceError_(f"burn-schedule '{pargs['burn-schedule']}' not understood")
-    pool = _Pool(pargs, factory=params_from_pargs)
-    if pargs.get("x0") is not None:
-        x0 = julia_vector(pargs["x0"])
-        if len(x0) == 2 * pargs["num-monomers"] and len(x0) != 2:      # inc/eap_chain.jl:73-75
-            dx0 = julia_vector(pargs["dx0"])
-            for e in pool.parts:
-                e.restart_from_x0(x0, dx0[0], dx0[1])
+    pool = _Pool(plist, factory=params_from_pargs)
     try:
+        if pargs.get("x0") is not None:
+            x0 = julia_vector(pargs["x0"])
+            if len(x0) == 2 * pargs["num-monomers"] and len(x0) != 2:      # inc/eap_chain.jl:73-75
+                dx0 = julia_vector(pargs["dx0"])
+                for e in pool.parts:
+                    e.restart_from_x0(x0, dx0[0], dx0[1])
         for mult in ladder:                                             # :366-383
-            _stage(pool, int(pargs["burn-in"]), pargs, pargs["kT"] * mult, write=False)
-        s = _stage(pool, int(pargs["num-steps"]), pargs, pargs["kT"], write=True)   # :385-386
-        pool.report_failures(pargs, s)
+            _stage(pool, int(pargs["burn-in"]), mult, write=False)
+        out = _stage(pool, int(pargs["num-steps"]), 1.0, write=write_csv)   # :385-386
+        for k, s in enumerate(out):
+            pool.report_failures(k, s)
+        if info is not None:
+            info["kernel"] = pool.kernel()
     finally:
         pool.close()
-    avg, se = np.array(s.avg), np.array(s.stderr)
-    ex, exse = np.array(s.extra_avg), np.array(s.extra_stderr)
-    sas = [Averager(avg[6], se[6]), Averager(avg[13], se[13]), Averager(avg[14], se[14]), Averager(avg[15], se[15]),
-           Averager(ex[0], exse[0]), Averager(ex[1], exse[1])]
-    vas = [Averager(avg[0:3], se[0:3]), Averager(avg[3:6], se[3:6]), Averager(avg[7:10], se[7:10]),
-           Averager(avg[10:13], se[10:13])]
-    return sas, vas, s.acceptance_ratio
+    res = []
+    for s in out:
+        sas, vas, ar = _averagers(s)
+        ex, exse = np.array(s.extra_avg), np.array(s.extra_stderr)
+        res.append((sas + [Averager(ex[0], exse[0]), Averager(ex[1], exse[1])], vas, ar))
+    return res
 
 
 def summary_lines(sas, vas, ar, pargs) -> list[str]:

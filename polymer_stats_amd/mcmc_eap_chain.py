@@ -173,29 +173,34 @@ def get_avg(a: Averager):
 
 
 class _Pool:
-    """Chains sharded over one or more devices in this process; reductions merged on the host
-    (every entry of the reduction vector is additive)."""
+    """The cases of one ensemble -- one for the command line, many for a sweep (polymer_stats_amd/sweep.py; they differ only
+    in their physics scalars, pstat_create) --, every case's chains sharded over one or more devices in this process;
+    reductions merged on the host (every entry of the reduction vector is additive)."""
 
-    def __init__(self, pargs: dict, factory=None):
+    def __init__(self, pargs, factory=None):
+        self.plist = plist = pargs if isinstance(pargs, list) else [pargs]
         factory = factory or params_from_pargs
-        resolve_seed(pargs)      # before the shards are made: every device gets the same seed, disjoint chain ids
-        self.numeric_type = pargs.get("numeric-type", "float64")
+        for p in plist:
+            resolve_seed(p)      # before the shards are made: every device gets the same seed, disjoint chain ids
+        p0 = plist[0]
+        self.numeric_type = p0.get("numeric-type", "float64")
         if self.numeric_type != "float64":
             # mcmc_eap_chain.jl:186-197 switches the averagers' accumulation type.  Here the per-chain sums are
             # Float64 on the device (the reference's default); what the option changes is the merge over chains.
-            _log(pargs, 2, "Warning", f"--numeric-type {self.numeric_type}: per-chain sums are Float64 on the device; the "
-                                      f"merge over chains is carried out in {WIDE_TYPES[self.numeric_type]}")
-        devices = [int(d) for d in str(pargs["devices"]).split(",") if d != ""]
-        total = int(pargs["num-chains"])
+            _log(p0, 2, "Warning", f"--numeric-type {self.numeric_type}: per-chain sums are Float64 on the device; the "
+                                   f"merge over chains is carried out in {WIDE_TYPES[self.numeric_type]}")
+        devices = [int(d) for d in str(p0["devices"]).split(",") if d != ""]
+        total = int(p0["num-chains"])
         if total < 1:
             raise ReferenceError_("num-chains must be >= 1")
         devices = devices[:total] or [0]
         base, extra = divmod(total, len(devices))
-        self.parts = []
+        self.parts, self.counts = [], []
         first = 0
         for i, dev in enumerate(devices):
             cnt = base + (1 if i < extra else 0)
-            self.parts.append(Ensemble(factory(pargs, cnt, first, dev)))
+            self.parts.append(Ensemble([factory(p, cnt, first, dev) for p in plist]))
+            self.counts.append(cnt)
             first += cnt
         self.steps = 0
 
@@ -208,39 +213,42 @@ class _Pool:
         for e in self.parts:
             e.reinit(force)
 
-    def burn_in(self, nsteps, multipliers, kT):
-        """Run the temperature ladder without keeping anything it records."""
+    def burn_in(self, nsteps, multipliers):
+        """Run the temperature ladder (every case's own kT times the rung's multiplier) without keeping anything it records."""
         for mult in multipliers:
             for e in self.parts:
-                e.set_kT(kT * mult)
+                e.scale_kT(mult)
             for e in self.parts:
                 e.advance(nsteps)
         for e in self.parts:
-            e.set_kT(kT)
+            e.scale_kT(1.0)
             e.reset_averages()
         self.steps = 0
 
-    def stage(self, kT):
-        """Start of a fresh mcmc(nsteps, pargs, chain) call of the clustering main: new temperature,
+    def stage(self, mult):
+        """Start of a fresh mcmc(nsteps, pargs, chain) call of the clustering main: new temperature (kT x mult),
         default step sizes, empty acceptor cache and averagers (mcmc_clustering_eap_chain.jl:172-181)."""
         for e in self.parts:
-            e.set_kT(kT)
+            e.scale_kT(mult)
             e.reset_sampler()
             e.reset_averages()
         self.steps = 0
 
-    def chain0(self):
-        return self.parts[0].chain_state(0)
+    def chain0(self, k=0):
+        return self.parts[0].chain_state(k * self.counts[0])      # the first chain of case k
 
-    def summary(self):
+    def microstate(self, k=0):
+        return self.parts[0].microstate(k * self.counts[0])
+
+    def summary(self, k=0):
         red = np.zeros(_lib.NRED)
         for e in self.parts:
-            red += e.reduce_host(-1)
+            red += e.reduce_host(k)
         s = summary_from_reduction(red, self.steps)
         if self.numeric_type != "float64":
             # --numeric-type: pooled mean and across-chain standard error re-done in the wide type from the per-chain
             # means (the same quantities the device reduction folds in Float64)
-            m = np.concatenate([e.chain_means(-1) for e in self.parts], axis=1).astype(np.longdouble)
+            m = np.concatenate([e.chain_means(k) for e in self.parts], axis=1).astype(np.longdouble)
             C = m.shape[1]
             mean = m.sum(axis=1) / C
             se = np.sqrt(((m - mean[:, None]) ** 2).sum(axis=1) / (C - 1) / C) if C > 1 else np.zeros_like(mean)
@@ -251,26 +259,44 @@ class _Pool:
                 s.extra_avg[q], s.extra_stderr[q] = float(mean[17 + q]), float(se[17 + q])
         return s
 
-    def report_failures(self, pargs, s):
+    def report_failures(self, k, s):
         """stderr only (stdout stays the reference's lines): what the reference hides -- proposals it rejected because
         their energy was NaN/Inf, and chains sitting in a 1/r^3 singularity (no excluded volume, inc/eap_chain.jl:200-207)."""
+        pargs = self.plist[k]
+        who = f"{os.path.basename(pargs['prefix'])}: " if len(self.plist) > 1 else ""
         if s.nan_rejects:
-            _log(pargs, 2, "Warning", f"{s.nan_rejects} proposals had a non-finite energy and were rejected "
+            _log(pargs, 2, "Warning", f"{who}{s.nan_rejects} proposals had a non-finite energy and were rejected "
                                       f"({s.nan_rejects / max(1.0, s.attempted_updates):.3g} of all attempts)")
         if s.chains_collapsed:
-            _log(pargs, 2, "Warning", f"{s.chains_collapsed} of {s.num_chains} chains have collapsed "
+            _log(pargs, 2, "Warning", f"{who}{s.chains_collapsed} of {s.num_chains} chains have collapsed "
                                       f"(|U| a thousand times beyond field + force + thermal energy: monomers on top of each other)")
 
-    def microstate(self):
-        return self.parts[0].microstate(0)
+    def kernel(self) -> str:
+        return self.parts[0].launch_info().kernel.decode()
 
     def close(self):
         for e in self.parts:
             e.close()
 
 
+def _averagers(s):
+    avg, se = np.array(s.avg), np.array(s.stderr)
+    sas = [Averager(avg[6], se[6]), Averager(avg[13], se[13]), Averager(avg[14], se[14]), Averager(avg[15], se[15])]
+    vas = [Averager(avg[0:3], se[0:3]), Averager(avg[3:6], se[3:6]), Averager(avg[7:10], se[7:10]),
+           Averager(avg[10:13], se[10:13])]
+    return sas, vas, s.acceptance_ratio
+
+
 def mcmc(nsteps: int, pargs: dict):
     """mcmc(nsteps, pargs) of mcmc_eap_chain.jl:171-376 -> (scalar_averagers, vector_averagers, ar)."""
+    return mcmc_cases(nsteps, [pargs])[0]
+
+
+def mcmc_cases(nsteps: int, plist: list, write_csv: bool = True, info: dict | None = None) -> list:
+    """mcmc(nsteps, pargs) for every case of `plist` at once -- parsed options that differ only in their physics scalars,
+    prefix and seed (one case: the command line; many: a sweep, polymer_stats_amd/sweep.py) -- as ONE ensemble: one launch
+    per segment for all of them.  `write_csv=False` skips the two CSV files of every case (then one launch per init)."""
+    pargs = plist[0]
     if pargs["acc"] != "metropolis":
         raise ReferenceError_(f"'{pargs['acc']}' acceptance criteria has not yet been implemented.")  # :184
     if pargs["numeric-type"] not in ("float64", "float128", "dec128", "big"):
@@ -278,48 +304,53 @@ def mcmc(nsteps: int, pargs: dict):
     if pargs["ensemble-type"] != "force":
         raise ReferenceError_("'end-to-end' ensemble is an experimental option of the reference; "
                               "it has no device implementation")
-    pool = _Pool(pargs)
-    stepout = int(pargs["stepout"])
-    if pargs["burn-in"] > 0:
-        ladder = [float(x) for x in pargs["burn-schedule"].strip("[] ").replace(",", ";").split(";") if x.strip()]
-        pool.burn_in(int(pargs["burn-in"]), ladder or [1.0], pargs["kT"])
+    pool = _Pool(plist)
+    stepout = int(pargs["stepout"]) if write_csv else 0
+    files = []
     try:
-        with open(f"{pargs['prefix']}_trajectory.csv", "w") as outfile, \
-                open(f"{pargs['prefix']}_rolling.csv", "w") as rollfile:
+        if pargs["burn-in"] > 0:
+            ladder = [float(x) for x in pargs["burn-schedule"].strip("[] ").replace(",", ";").split(";") if x.strip()]
+            pool.burn_in(int(pargs["burn-in"]), ladder or [1.0])
+        for p in plist if write_csv else []:
+            outfile, rollfile = open(f"{p['prefix']}_trajectory.csv", "w"), open(f"{p['prefix']}_rolling.csv", "w")
+            files.append((outfile, rollfile))
             outfile.write(TRAJ_HEADER + "\n")       # :257
             rollfile.write(ROLL_HEADER + "\n")      # :259
-            start = last_update = time.time()
-            for init in range(1, pargs["num-inits"] + 1):           # :266
-                step = 0
-                while step < nsteps:                                # :276 (in segments)
-                    seg = nsteps - step
-                    if stepout > 0:
-                        seg = min(seg, stepout - step % stepout)
-                    pool.advance(seg)
-                    step += seg
-                    if time.time() - last_update > pargs["update-freq"]:   # :294-299
-                        _log(pargs, 3, "Info", f"elapsed: {time.time() - start}")
-                        _log(pargs, 3, "Info", f"init:    {init} / {pargs['num-inits']}")
-                        _log(pargs, 3, "Info", f"step:    {step} / {nsteps}")
-                        last_update = time.time()
-                    if stepout > 0 and step % stepout == 0:          # :329-348
-                        micro = pool.microstate()
-                        s = pool.summary()
+        start = last_update = time.time()
+        for init in range(1, pargs["num-inits"] + 1):           # :266
+            step = 0
+            while step < nsteps:                                # :276 (in segments)
+                seg = nsteps - step
+                if stepout > 0:
+                    seg = min(seg, stepout - step % stepout)
+                pool.advance(seg)
+                step += seg
+                if time.time() - last_update > pargs["update-freq"]:   # :294-299
+                    _log(pargs, 3, "Info", f"elapsed: {time.time() - start}")
+                    _log(pargs, 3, "Info", f"init:    {init} / {pargs['num-inits']}")
+                    _log(pargs, 3, "Info", f"step:    {step} / {nsteps}")
+                    last_update = time.time()
+                if stepout > 0 and step % stepout == 0:          # :329-348
+                    for k, (outfile, rollfile) in enumerate(files):
+                        micro = pool.microstate(k)
+                        s = pool.summary(k)
                         outfile.write(jl_row([step, *micro]) + "\n")
                         rollfile.write(jl_row([step, *s.avg]) + "\n")
-                if init < pargs["num-inits"]:                        # :352-361
-                    pool.reinit(bool(pargs["force-init"]))
-        s = pool.summary()
+            if init < pargs["num-inits"]:                        # :352-361
+                pool.reinit(bool(pargs["force-init"]))
+        out = [pool.summary(k) for k in range(len(plist))]
         _log(pargs, 3, "Info", f"total time elapsed: {time.time() - start}")
-        _log(pargs, 3, "Info", f"acceptance rate: {s.acceptance_ratio}")
-        pool.report_failures(pargs, s)
+        for k, s in enumerate(out):
+            _log(plist[k], 3, "Info", f"acceptance rate: {s.acceptance_ratio}")
+            pool.report_failures(k, s)
+        if info is not None:
+            info["kernel"] = pool.kernel()
     finally:
+        for outfile, rollfile in files:
+            outfile.close()
+            rollfile.close()
         pool.close()
-    avg, se = np.array(s.avg), np.array(s.stderr)
-    sas = [Averager(avg[6], se[6]), Averager(avg[13], se[13]), Averager(avg[14], se[14]), Averager(avg[15], se[15])]
-    vas = [Averager(avg[0:3], se[0:3]), Averager(avg[3:6], se[3:6]), Averager(avg[7:10], se[7:10]),
-           Averager(avg[10:13], se[10:13])]
-    return sas, vas, s.acceptance_ratio
+    return [_averagers(s) for s in out]
 
 
 def summary_lines(sas, vas, ar, pargs) -> list[str]:

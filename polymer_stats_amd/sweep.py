@@ -8,9 +8,9 @@ writes the ten (twelve) stdout lines to `workdir/<name>.out` unless that file al
 then reads the values back out of the file NAMES and the stdout lines.
 
 Here the cases of a sweep that share everything but their physics scalars become ONE ensemble (`pstat_create` with
-ncases > 1) and one launch per stage of the main's protocol; cases are dealt to ranks round-robin (independent work, no
-exchange -- `pmap`'s own partitioning), and every case's `.out` holds exactly the lines the single-case host
-(`mcmc_eap_chain.py`, `mcmc_clustering_eap_chain.py`) prints for the same options, seed and chains.
+ncases > 1) and one launch per stage of the main's protocol -- the hosts' own `mcmc_cases` / `run_cases`, which the command
+line calls with one case --; cases are dealt to ranks round-robin (independent work, no exchange: `pmap`'s own partitioning),
+and every case's `.out` holds exactly the lines the single-case host prints for the same options, seed and chains.
 
     python tools/run_sweep.py WORKDIR --main mcmc_clustering_eap_chain --num-chains 64 \
         --axis run=1:5 --axis kT='10^(-2:0.2:2)' --axis E0=0:0.2:5 --axis K1=1 --axis K2=0 --axis Fz=0 --axis Fx=0 \
@@ -31,9 +31,7 @@ import numpy as np
 from . import _lib
 from . import mcmc_clustering_eap_chain as cluster_main
 from . import mcmc_eap_chain as fixed_main
-from .ensemble import Ensemble, summary_from_reduction
-from .julia_fmt import jl_row
-from .mcmc_eap_chain import Averager, ReferenceError_, _log
+from .mcmc_eap_chain import ReferenceError_
 
 MAINS = {"mcmc_eap_chain": fixed_main, "mcmc_clustering_eap_chain": cluster_main}
 
@@ -171,168 +169,9 @@ def case_argv(case: dict) -> list[str]:
     return argv
 
 
-# ---------------------------------------------------------------------------------------------- one batched group
-class _Batch:
-    """The cases of one ensemble on one device: what `_Pool` is for one case."""
-
-    def __init__(self, main, plist: list[dict], device: int):
-        self.main, self.plist = main, plist
-        C = int(plist[0]["num-chains"])
-        if C < 1:
-            raise ReferenceError_("num-chains must be >= 1")
-        self.e = Ensemble([main.params_from_pargs(p, C, 0, device) for p in plist])
-        self.C = C
-        self.steps = 0
-
-    def advance(self, n):
-        self.e.advance(n)
-        self.steps += n
-
-    def summary(self, k: int):
-        p = self.plist[k]
-        s = summary_from_reduction(self.e.reduce_host(k), self.steps)
-        if p.get("numeric-type", "float64") != "float64":       # the merge over chains in the wide type (_Pool.summary)
-            m = self.e.chain_means(k).astype(np.longdouble)
-            mean = m.sum(axis=1) / self.C
-            se = np.sqrt(((m - mean[:, None]) ** 2).sum(axis=1) / (self.C - 1) / self.C) if self.C > 1 else np.zeros_like(mean)
-            for q in range(_lib.NOBS):
-                s.avg[q], s.stderr[q] = float(mean[q]), float(se[q])
-            s.acceptance_ratio, s.ar_stderr = float(mean[16]), float(se[16])
-            for q in range(2):
-                s.extra_avg[q], s.extra_stderr[q] = float(mean[17 + q]), float(se[17 + q])
-        return s
-
-    def report_failures(self, k, s):
-        p = self.plist[k]
-        if s.nan_rejects:
-            _log(p, 2, "Warning", f"{os.path.basename(p['prefix'])}: {s.nan_rejects} proposals had a non-finite energy and were rejected")
-        if s.chains_collapsed:
-            _log(p, 2, "Warning", f"{os.path.basename(p['prefix'])}: {s.chains_collapsed} of {s.num_chains} chains have collapsed")
-
-    def close(self):
-        self.e.close()
-
-
-class _Csv:
-    """<prefix>_trajectory.csv / <prefix>_rolling.csv of every case of a batch (only with write_csv)."""
-
-    def __init__(self, batch: _Batch, clustering: bool):
-        self.b, self.clustering = batch, clustering
-        self.files = []
-        for p in batch.plist:
-            t, r = open(f"{p['prefix']}_trajectory.csv", "w"), open(f"{p['prefix']}_rolling.csv", "w")
-            if clustering:
-                t.write(cluster_main.traj_header(p["num-monomers"]) + "\n")
-                r.write(cluster_main.ROLL_HEADER + "\n")
-            else:
-                t.write(fixed_main.TRAJ_HEADER + "\n")
-                r.write(fixed_main.ROLL_HEADER + "\n")
-            self.files.append((t, r))
-
-    def row(self, step):
-        b = self.b
-        for k, (t, r) in enumerate(self.files):
-            first = k * b.C                                     # the case's first chain is the one whose microstate is printed
-            micro = b.e.microstate(first)
-            s = b.summary(k)
-            if self.clustering:
-                st = b.e.chain_state(first)
-                mus = cluster_main._dipoles(b.plist[k], st["phi"], st["theta"])
-                angles = np.stack([st["phi"], st["theta"]], axis=1).reshape(-1)
-                t.write(jl_row([step, *micro, *angles, *mus.reshape(-1)]) + "\n")
-                r.write(jl_row([step, *s.avg, *s.extra_avg]) + "\n")
-            else:
-                t.write(jl_row([step, *micro]) + "\n")
-                r.write(jl_row([step, *s.avg]) + "\n")
-
-    def close(self):
-        for t, r in self.files:
-            t.close()
-            r.close()
-
-
-def _segments(batch, nsteps, stepout, csv):
-    step = 0
-    while step < nsteps:
-        seg = nsteps - step
-        if csv is not None and stepout > 0:
-            seg = min(seg, stepout - step % stepout)
-        batch.advance(seg)
-        step += seg
-        if csv is not None and stepout > 0 and step % stepout == 0:
-            csv.row(step)
-
-
-def _run_fixed(batch: _Batch, write_csv: bool):
-    """mcmc(nsteps, pargs) of mcmc_eap_chain.jl:171-376 for every case of the batch at once (mcmc_eap_chain.mcmc)."""
-    p = batch.plist[0]
-    if p["acc"] != "metropolis":
-        raise ReferenceError_(f"'{p['acc']}' acceptance criteria has not yet been implemented.")
-    if p["ensemble-type"] != "force":
-        raise ReferenceError_("'end-to-end' ensemble is an experimental option of the reference; it has no device implementation")
-    if p["burn-in"] > 0:
-        ladder = cluster_main.julia_vector(p["burn-schedule"]) or [1.0]
-        for mult in ladder:
-            batch.e.scale_kT(mult)
-            batch.e.advance(int(p["burn-in"]))
-        batch.e.scale_kT(1.0)
-        batch.e.reset_averages()
-    csv = _Csv(batch, False) if write_csv else None
-    try:
-        for init in range(1, p["num-inits"] + 1):
-            _segments(batch, int(p["num-steps"]), int(p["stepout"]), csv)
-            if init < p["num-inits"]:
-                batch.e.reinit(bool(p["force-init"]))
-    finally:
-        if csv:
-            csv.close()
-
-
-def _run_clustering(batch: _Batch, write_csv: bool):
-    """mcmc_clustering_eap_chain.jl:354-387 for every case of the batch at once (mcmc_clustering_eap_chain.run)."""
-    p = batch.plist[0]
-    try:
-        ladder = cluster_main.julia_vector(p["burn-schedule"])
-    except (ValueError, SyntaxError):
-        raise ReferenceError_(f"burn-schedule '{p['burn-schedule']}' not understood")
-    if p.get("x0") is not None:
-        x0 = cluster_main.julia_vector(p["x0"])
-        if len(x0) == 2 * p["num-monomers"] and len(x0) != 2:
-            dx0 = cluster_main.julia_vector(p["dx0"])
-            batch.e.restart_from_x0(x0, dx0[0], dx0[1])
-
-    def stage(mult):                 # a fresh mcmc(nsteps, pargs, chain) call: _Pool.stage for every case's own kT
-        batch.e.scale_kT(mult)
-        batch.e.reset_sampler()
-        batch.e.reset_averages()
-        batch.steps = 0
-
-    for mult in ladder:
-        stage(mult)
-        batch.advance(int(p["burn-in"]))
-    stage(1.0)
-    csv = _Csv(batch, True) if write_csv else None
-    try:
-        _segments(batch, int(p["num-steps"]), int(p["stepout"]), csv)
-    finally:
-        if csv:
-            csv.close()
-
-
-def _lines(main, s, pargs) -> list[str]:
-    avg, se = np.array(s.avg), np.array(s.stderr)
-    sas = [Averager(avg[6], se[6]), Averager(avg[13], se[13]), Averager(avg[14], se[14]), Averager(avg[15], se[15])]
-    if main is cluster_main:
-        ex, exse = np.array(s.extra_avg), np.array(s.extra_stderr)
-        sas += [Averager(ex[0], exse[0]), Averager(ex[1], exse[1])]
-    vas = [Averager(avg[0:3], se[0:3]), Averager(avg[3:6], se[3:6]), Averager(avg[7:10], se[7:10]),
-           Averager(avg[10:13], se[10:13])]
-    return main.summary_lines(sas, vas, s.acceptance_ratio, pargs)
-
-
 # ---------------------------------------------------------------------------------------------- the sweep
 def plan(main_name: str, fixed_argv: list[str], cases: list[dict], workdir: str, *, name=None, num_chains: int = 64,
-         seed: int | None = None, precision: str | None = None, rng: str | None = None) -> list[dict]:
+         seed: int | None = None, precision: str | None = None, rng: str | None = None, device: int = 0) -> list[dict]:
     """Every case's parsed options (the dict the main's own parser returns) with its prefix, its `.out` path and its
     seed = base seed + position in the FULL case list (so a case's result depends neither on which other cases still
     have to be run nor on how many ranks share them)."""
@@ -341,7 +180,7 @@ def plan(main_name: str, fixed_argv: list[str], cases: list[dict], workdir: str,
         return []
     spec = name_spec(name, list(cases[0].keys()))
     base = fixed_main.fresh_seed() & 0x7FFFFFFFFFFF if seed is None else int(seed)
-    extra = ["--num-chains", str(int(num_chains))]
+    extra = ["--num-chains", str(int(num_chains)), "--devices", str(int(device))]
     if precision:
         extra += ["--precision", precision]
     if rng:
@@ -373,7 +212,7 @@ def run_sweep(main_name: str, fixed_argv: list[str], cases: list[dict], workdir:
     main = MAINS[main_name]
     os.makedirs(workdir, exist_ok=True)
     todo_all = plan(main_name, fixed_argv, cases, workdir, name=name, num_chains=num_chains, seed=seed, precision=precision,
-                    rng=rng)
+                    rng=rng, device=device)
     skipped = [p["_name"] for p in todo_all if os.path.isfile(p["_out"]) and not overwrite]
     todo = [p for p in todo_all if overwrite or not os.path.isfile(p["_out"])]
     mine = [p for p in todo if p["_index"] % world == rank]     # by position in the full list: ranks need not agree on what is done
@@ -386,24 +225,21 @@ def run_sweep(main_name: str, fixed_argv: list[str], cases: list[dict], workdir:
         for i in range(0, len(plist_all), per_launch):
             plist = plist_all[i:i + per_launch]
             t0 = time.time()
-            batch = _Batch(main, plist, device)
-            try:
-                (_run_clustering if main is cluster_main else _run_fixed)(batch, write_csv)
-                for k, p in enumerate(plist):
-                    s = batch.summary(k)
-                    batch.report_failures(k, s)
-                    tmp = p["_out"] + f".tmp{os.getpid()}"
-                    with open(tmp, "w") as f:           # println x 10 (12); complete or absent: an interrupted sweep re-runs the case
-                        f.write("\n".join(_lines(main, s, p)) + "\n")
-                    os.replace(tmp, p["_out"])
-                    ran.append(p["_name"])
-                info = batch.e.launch_info()
-            finally:
-                batch.close()
+            info = {}
+            if main is cluster_main:      # the main's own protocol, every case of the ensemble at once
+                res = main.run_cases(plist, write_csv=write_csv, info=info)
+            else:
+                res = main.mcmc_cases(int(plist[0]["num-steps"]), plist, write_csv=write_csv, info=info)
+            for p, (sas, vas, ar) in zip(plist, res):
+                tmp = p["_out"] + f".tmp{os.getpid()}"
+                with open(tmp, "w") as f:           # println x 10 (12); complete or absent: an interrupted sweep re-runs the case
+                    f.write("\n".join(main.summary_lines(sas, vas, ar, p)) + "\n")
+                os.replace(tmp, p["_out"])
+                ran.append(p["_name"])
             launches += 1
             if log:
                 log(f"rank {rank}: {len(plist)} cases x {num_chains} chains, n = {plist[0]['num-monomers']}, "
-                    f"{info.kernel.decode()}: {time.time() - t0:.2f} s")
+                    f"{info.get('kernel', '?')}: {time.time() - t0:.2f} s")
     return {"ran": ran, "skipped": skipped, "launches": launches}
 
 
