@@ -23,12 +23,11 @@ import ast
 import itertools
 import json
 import os
-import sys
 import time
 
 import numpy as np
 
-from . import _lib
+from . import _lib          # (tools/run_sweep.py counts the devices through it)
 from . import mcmc_clustering_eap_chain as cluster_main
 from . import mcmc_eap_chain as fixed_main
 from .mcmc_eap_chain import ReferenceError_
