@@ -164,7 +164,8 @@ def case_argv(case: dict) -> list[str]:
     for k, v in case.items():
         flag = KEY_FLAG.get(k, f"--{k}")
         if flag is not None:
-            argv += [flag, repr(int(v)) if flag == "--num-monomers" else repr(float(v))]
+            whole = isinstance(v, int) or (flag == "--num-monomers" and float(v).is_integer())
+            argv += [flag, repr(int(v)) if whole else repr(float(v))]      # (an integer option of the main may be an axis too)
     return argv
 
 

@@ -60,6 +60,10 @@ def test_plan_builds_the_mains_own_options(tmp_path):
     assert pl[0]["prefix"] == str(tmp_path / "E0-0001000_K1-0000000_K2-0001000_kT-0000100_Fz-0000000_Fx-0001000_n-0100000_b-0000500_kappa-0000000_run-001")
     assert pl[1]["_out"].endswith("_run-002.out")
     assert sw._signature(pl[0]) == sw._signature(pl[1]) != sw._signature(pl[2])               # one ensemble per chain length
+    # any option of the main can be an axis, integer ones included; its key is then the option's own name
+    pl2 = sw.plan("mcmc_clustering_eap_chain", fixed, [dict(E0=1, n=50.0, **{"num-steps": 4000, "cluster-prob": 0.25})], str(tmp_path), seed=1)
+    assert pl2[0]["num-steps"] == 4000 and pl2[0]["cluster-prob"] == 0.25 and pl2[0]["num-monomers"] == 50
+    assert pl2[0]["_name"] == "E0-0001000_n-0050000_num-steps-4000000_cluster-prob-0000250"
     with pytest.raises(ValueError, match="share the file name"):
         sw.plan("mcmc_clustering_eap_chain", fixed, cases, str(tmp_path), name="E0,K1", seed=1)
     with pytest.raises(SystemExit):                      # the fixed-force main has no --bend-mod: its own parser says so
