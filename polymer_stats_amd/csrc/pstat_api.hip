@@ -409,7 +409,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   CREATE_TRY(alloc(h, (void **)&S.nanrej, Cz * sizeof(int64_t)));
   const size_t nstate = h->bufs.size();
   CREATE_TRY(alloc(h, &S.ang_tmp, 2 * n * Cz * h->elem));
-  if (cluster_gm)            // working copy of the chains, [chain block][lane][n] 48-byte cells (pstat_cluster_gm.hip)
+  if (cluster_gm)            // working copy of the chains, [chain block][lane][n] cells of 40 (f64) / 20 (f32) bytes (pstat_cluster_gm.hip)
     CREATE_TRY(alloc(h, &S.work, cluster_gm_work_bytes(h->cfg, A)));
   else if (h->cfg.state_global)   // working copy of the cells, [chain block][n][64] double2 (run_segment, ST = 2)
     CREATE_TRY(alloc(h, &S.work, (size_t)(A.blocks_per_case * ncases) * n * 64 * 16));
