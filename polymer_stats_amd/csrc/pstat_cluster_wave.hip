@@ -196,8 +196,11 @@ void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ 
     for (int k = 0; k < (int)chunk; ++k) {
       // ---- the single-monomer part of the proposal, mcmc_clustering_eap_chain.jl:269-272
       const int idx = (int)__umulhi(g.next(), (uint32_t)n);
-      const R dphi = phistep * sym11<R>(g.next());
-      const R dth = thstep * sym11<R>(g.next());
+      // (the trajectory itself: each product rounded before its sum -- through an opaque register, so that no build flag
+      // can fuse them; cf. run_segment)
+      auto rounded = [](R v) __attribute__((always_inline)) -> R { asm volatile("" : "+v"(v)); return v; };
+      const R dphi = rounded(phistep * sym11<R>(g.next()));
+      const R dth = rounded(thstep * sym11<R>(g.next()));
       const R th0 = at(cur.th, idx), ph0 = at(cur.ph, idx);
       const R ph1 = AG::wrap(ph0 + dphi);
       const R th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));

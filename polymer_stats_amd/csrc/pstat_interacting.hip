@@ -226,11 +226,14 @@ __global__ __launch_bounds__(64, M == 8 ? PSTAT_IOCC_M8 :
       // ---- proposal (wave-uniform), mcmc_eap_chain.jl:277-280
       const int idx = (int)__umulhi(g.next(), (uint32_t)n);
       const int owner = idx / M, slot = idx % M;
-      const R dphi = phistep * sym11<R>(g.next());
+      // (the trajectory itself: each product rounded before its sum, as the oracle and Julia round them -- through an
+      // opaque register, so that no build flag can fuse them; cf. run_segment)
+      auto rounded = [](R v) __attribute__((always_inline)) -> R { asm volatile("" : "+v"(v)); return v; };
+      const R dphi = rounded(phistep * sym11<R>(g.next()));
       const R th0 = at_idx(th, owner, slot), ph0 = at_idx(ph, owner, slot);
       R flip = 0;
-      if (do_flips && (g.next() >> 31)) flip = AG::theta_max - 2 * th0;
-      const R dth = flip + thstep * sym11<R>(g.next());
+      if (do_flips && (g.next() >> 31)) flip = AG::theta_max - rounded(2 * th0);
+      const R dth = flip + rounded(thstep * sym11<R>(g.next()));
       const uint32_t weps = g.next();
       const R eps = u01<R>(weps);
       (void)eps;
