@@ -519,7 +519,7 @@ ClusterFn pick_ct_en(const LaunchCfg &cfg) {
 }  // namespace
 
 // Two objects are built from this file (csrc/Makefile): -DPSTAT_CPART=1 holds the f32 and q16 instantiations
-// and is compiled with -ffp-contract=fast (statistical parity only), -DPSTAT_CPART=2 the f64 ones and the
+// and is compiled with -ffp-contract=fast (statistical parity only), -DPSTAT_CPART=2 the f64 ones (LDS home: the literal witness, see the Makefile) and the
 // launchers with -ffp-contract=off (bit parity with the oracle).  Without the macro: everything in one object.
 #if !defined(PSTAT_CPART) || PSTAT_CPART == 1
 ClusterFn pick_cluster_f32(const LaunchCfg &cfg) {

@@ -370,9 +370,9 @@ WaveFn pick_m(const LaunchCfg &cfg, int64_t n) {
 
 }  // namespace
 
-// Two objects are built from this file (csrc/Makefile): -DPSTAT_WPART=1 holds the f32 instantiations, compiled
-// with -ffp-contract=fast (statistical parity only); -DPSTAT_WPART=2 the f64 ones and the launchers with
-// -ffp-contract=off (bit parity with the oracle).  Without the macro: everything in one object.
+// Two objects are built from this file (csrc/Makefile): -DPSTAT_WPART=1 holds the f32 instantiations
+// (statistical parity only), -DPSTAT_WPART=2 the f64 ones (bit parity with the oracle) and the launchers; both with
+// -ffp-contract=fast -- the f64 proposal arithmetic is fenced, see the note in the Makefile.  Without the macro: everything in one object.
 #if !defined(PSTAT_WPART) || PSTAT_WPART == 1
 WaveFn pick_wave_f32(const LaunchCfg &cfg, int64_t n) {
   return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_m<float, Xoshiro128pp>(cfg, n) : pick_m<float, Mwc64x>(cfg, n);

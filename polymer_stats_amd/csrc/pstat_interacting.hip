@@ -386,9 +386,9 @@ static InterFn pick_interacting_m(const LaunchCfg &cfg, int64_t n) {
   return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 8> : interacting_kernel<R, G, PSTAT_POLAR, 8>;
 }
 
-// Two objects are built from this file (csrc/Makefile): -DPSTAT_IPART=1 holds the f32 instantiations, compiled
-// with -ffp-contract=fast (statistical parity only); -DPSTAT_IPART=2 the f64 ones and the launchers with
-// -ffp-contract=off (bit parity with the oracle).  Without the macro: everything in one object.
+// Two objects are built from this file (csrc/Makefile): -DPSTAT_IPART=1 holds the f32 instantiations
+// (statistical parity only), -DPSTAT_IPART=2 the f64 ones (bit parity with the oracle) and the launchers; both with
+// -ffp-contract=fast -- the f64 proposal arithmetic is fenced, see the note in the Makefile.  Without the macro: everything in one object.
 #if !defined(PSTAT_IPART) || PSTAT_IPART == 1
 InterFn pick_interacting_f32(const LaunchCfg &cfg, int64_t n) {
   return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_interacting_m<float, Xoshiro128pp>(cfg, n)
