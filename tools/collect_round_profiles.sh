@@ -15,6 +15,9 @@ run ${tag}_bench_f32 bench.py --steps 3 --warmup 1 --no-cpu-baseline --precision
 # the clustering main, chain per lane (f64: chains in device memory), n = 100
 run ${tag}_cluster_f64_ni tools/profile_cluster.py ni f64 5000 2
 run ${tag}_cluster_f64_ising tools/profile_cluster.py ising f64 5000 2
+# the same main in f32: cells in LDS (n = 100), and the in-memory home that 65 536 chains of n = 200 get by default
+run ${tag}_cluster_f32_ni tools/profile_cluster.py ni f32 5000 2
+run ${tag}_cluster_f32_mem_n200 tools/profile_cluster.py ni f32 5000 2 200
 # the all-pairs kernels in f64: fixed-force main n = 64 (BASELINE configs[3]), clustering main n = 100
 run ${tag}_interacting_f64_n64 tools/profile_interacting.py 64 f64 4000 2
 run ${tag}_cluster_wave_f64_n100 tools/profile_cluster.py interacting f64 1000 2

@@ -7,6 +7,9 @@ $S gpurun_out/prof_${tag}_bench_f64 profiles/$tag bench_f64 --kernel sweep_kerne
 $S gpurun_out/prof_${tag}_bench_f32 profiles/$tag bench_f32 --kernel sweep_kernel --updates 6553600000 --record f32_n100_c65536_s100000 > /dev/null
 $S gpurun_out/prof_${tag}_cluster_f64_ni profiles/$tag cluster_f64_ni --kernel cluster --updates 327680000 > /dev/null
 $S gpurun_out/prof_${tag}_cluster_f64_ising profiles/$tag cluster_f64_ising --kernel cluster --updates 327680000 > /dev/null
+for w in cluster_f32_ni cluster_f32_mem_n200; do
+  if [ -d gpurun_out/prof_${tag}_$w ]; then $S gpurun_out/prof_${tag}_$w profiles/$tag $w --kernel cluster --updates 327680000 > /dev/null; fi
+done
 $S gpurun_out/prof_${tag}_interacting_f64_n64 profiles/$tag interacting_f64_n64 --kernel interacting_kernel --updates 65536000 > /dev/null
 $S gpurun_out/prof_${tag}_cluster_wave_f64_n100 profiles/$tag cluster_wave_f64_n100 --kernel cluster_wave --updates 16384000 > /dev/null
 $S gpurun_out/prof_${tag}_sweep_f64_ising_n200 profiles/$tag sweep_f64_ising_n200 --kernel sweep_kernel --updates 1310720000 > /dev/null
