@@ -77,11 +77,12 @@ constexpr int XREQ = PSTAT_GM_XREQ;
 #define PSTAT_GM_D 2
 #endif
 constexpr int D = PSTAT_GM_D;        // rows in flight per end once a cluster has outgrown those
+constexpr int NS = D + 1;            // register sets of the ring: D rows in flight + the set of the previous round's row
 #ifndef PSTAT_GM_CAPT
-#define PSTAT_GM_CAPT 8
+#define PSTAT_GM_CAPT 9
 #endif
-constexpr int CAPT = PSTAT_GM_CAPT;  // ring rounds that still capture the boundary monomers (a multiple of D)
-static_assert(CAPT % D == 0, "whole ring trips");
+constexpr int CAPT = PSTAT_GM_CAPT;  // ring rounds that still capture the boundary monomers (a multiple of NS)
+static_assert(CAPT % NS == 0, "whole ring trips");
 static_assert(XREQ < W, "the outer rows are requested inside the window rounds");
 constexpr uint32_t OOB = 0x80000000u;  // past every working buffer (num_records < 2^31, checked by the host): no access
 
@@ -399,8 +400,8 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
         }
         if (__builtin_amdgcn_ballot_w64(gu || gl) != 0) {
           // (the ring of the rounds beyond W + E - 1, see below: rows W + E + 1 .. W + E + D, asked for by the ends that enter round W)
-          P2 ra[D], rb[D], sa[D], sb[D];
-          int ring = W + E + 1;      // row offset of ring set 0's current row
+          P2 ra[NS], rb[NS], sa[NS], sb[NS];
+          int ring = W + E + 1;      // row offset of the next ring round's candidate row
 #pragma unroll
           for (int k = 0; k < D; ++k) {
             uint32_t q = up_off(idx + ring + k, gu);
@@ -420,35 +421,41 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
             Al = Bl;
           }
           // ---- beyond: one end in 2^(W + E) gets here -- rarely in a disordered chain, every step in an aligned one
-          // (cold or stiff: every link joins, clusters run to the chain ends).  A ring of D register sets, each row
-          // requested D rounds before its round; the ring was first filled when these ends entered round W.
+          // (cold or stiff: every link joins, clusters run to the chain ends).  A ring of NS = D + 1 register sets: each row is
+          // requested D rounds before its round (the first D when these ends entered round W), and the set of the round
+          // before still holds this round's outermost member.
           // The boundary monomers are captured round by round for the first CAPT rounds (a disordered chain's tail is a
           // round or two: no further memory phase); an end that grows on drops the capture -- a fifth of the round's
           // instructions, for tens of rounds -- and reads its two boundary monomers back when it has stopped.
+          // A round's outermost member A is the candidate B of the round before: it is read out of THAT round's register set
+          // (no copy: a lone wave pays four cycles for every move), which is then free and requests the row D rounds out.
+          // The first ring round finds the outermost member of the rounds so far in the spare set.
+          ra[D] = P2{Au.x, Au.y}; rb[D] = P2{Au.z, (R)0};
+          sa[D] = P2{Al.x, Al.y}; sb[D] = P2{Al.z, (R)0};
           auto ring_round = [&](const int k, const bool cap) __attribute__((always_inline)) {
+            const int ka = (k + NS - 1) % NS;
+            const T3 Au_ = nhat(ra[ka], rb[ka]), Al_ = nhat(sa[ka], sb[ka]);
             const T3 Bu = nhat(ra[k], rb[k]), Bl = nhat(sa[k], sb[k]);
             const bool eBu = is_edge(rb[k].y), eBl = is_edge(sb[k].y);
-            if (cap) capture(gu, Au, Bu, cu, nu);
-            half_round(true, gu, Au, Bu, eBu, upper_p, upper);
-            Au = Bu;
-            if (cap) capture(gl, Al, Bl, cl, nl);
-            half_round(false, gl, Al, Bl, eBl, lower_p, lower);
-            Al = Bl;
-            ring += 1;      // this set is free again: its next row is D rounds out
-            uint32_t q = up_off(idx + ring + D - 1, gu);
-            ra[k] = ld(q); rb[k] = ld(q + HB);
-            q = dn_off(idx - ring - D + 1, gl);
-            sa[k] = ld(q); sb[k] = ld(q + HB);
+            if (cap) capture(gu, Au_, Bu, cu, nu);
+            half_round(true, gu, Au_, Bu, eBu, upper_p, upper);
+            if (cap) capture(gl, Al_, Bl, cl, nl);
+            half_round(false, gl, Al_, Bl, eBl, lower_p, lower);
+            uint32_t q = up_off(idx + ring + D, gu);      // set ka is free: its next row is D rounds out
+            ra[ka] = ld(q); rb[ka] = ld(q + HB);
+            q = dn_off(idx - ring - D, gl);
+            sa[ka] = ld(q); sb[ka] = ld(q + HB);
+            ring += 1;
           };
-          for (int trip = 0; trip < CAPT / D && (gu || gl); ++trip) {
+          for (int trip = 0; trip < CAPT / NS && (gu || gl); ++trip) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) ring_round(k, true);
+            for (int k = 0; k < NS; ++k) ring_round(k, true);
           }
           const bool longu = gu, longl = gl;     // still growing after the captured rounds
           if (__builtin_amdgcn_ballot_w64(longu || longl) != 0) {
             while (gu || gl) {
 #pragma unroll
-              for (int k = 0; k < D; ++k) ring_round(k, false);
+              for (int k = 0; k < NS; ++k) ring_round(k, false);
             }
             uint32_t o = longu ? row_off(upper) : OOB;
             P2 ta = ld(o), tb = ld(o + HB);
