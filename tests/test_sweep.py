@@ -108,6 +108,12 @@ def test_run_sweep_cli_needs_cases_and_a_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_sweep.py"), str(tmp_path)], capture_output=True, text=True)
     assert r.returncode != 0 and "no cases" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_sweep.py"), str(tmp_path / "d"), "--dry-run", "--axis", "b=0.5,1,2",
+                        "--axis", "n=100,200", "--axis", "E0=0.1,1,10", "--axis", "K1=0,1", "--axis", "K2=0,1", "--skip", "K1==K2",
+                        "--num-chains", "4", "--", "--energy-type", "interacting", "--num-steps", "500000", "-v", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "36 cases (0 already there), 2 ensemble(s)" in r.stdout and "n = 200, interacting, dielectric, 500000 steps: 18 cases, 72 chains" in r.stdout
+    assert "E0-0000100_K1-0000000_K2-0001000_n-0100000_b-0000500.out" in r.stdout and not (tmp_path / "d").exists()
     import polymer_stats_amd as ps
     if ps._lib.load().pstat_device_count() < 1:           # the product has no CPU path: say so, write nothing
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_sweep.py"), str(tmp_path / "w"), "--axis", "n=10"],

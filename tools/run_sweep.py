@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--overwrite", action="store_true")
     ap.add_argument("--csv", action="store_true", help="also write every case's _trajectory.csv and _rolling.csv (launches split at --stepout)")
     ap.add_argument("--max-chains", type=int, default=262144, help="chains per launch (cases per ensemble = this / num-chains)")
+    ap.add_argument("--dry-run", action="store_true", help="print the plan (cases, file names, ensembles) and stop: no GPU needed")
     ap.add_argument("--aggregate", default="", help="afterwards write scripts/aggregate_mcmc.jl's CSV of the whole directory here")
     ap.add_argument("--aggregate-args", default="*.out,dielectric", help="pattern,dielectric|polar[,kappaflag[,runflag]]")
     args = ap.parse_args(argv)
@@ -66,6 +67,22 @@ def main():
     if not cases:
         raise SystemExit("no cases: give --axis and/or --cases")
 
+    if args.dry_run:
+        pl = sw.plan(args.main, fixed, cases, args.workdir, name=args.name or None, num_chains=args.num_chains,
+                     seed=0 if args.seed is None else args.seed, precision=args.precision, rng=args.rng)
+        groups = {}
+        for p in pl:
+            groups.setdefault(sw._signature(p), []).append(p)
+        done = sum(os.path.isfile(p["_out"]) for p in pl)
+        print(f"{len(pl)} cases ({done} already there), {len(groups)} ensemble(s) per rank at most, {args.num_chains} chain(s) per case, "
+              f"{args.gpus} rank(s); main {args.main}; seed {'fresh entropy' if args.seed is None else args.seed} + position")
+        for g in groups.values():
+            p0 = g[0]
+            print(f"  n = {p0['num-monomers']}, {p0['energy-type']}, {p0['chain-type']}, {p0['num-steps']} steps: {len(g)} cases, "
+                  f"{len(g) * args.num_chains} chains")
+        for p in pl[:3] + (pl[-1:] if len(pl) > 3 else []):
+            print("  " + os.path.basename(p["_out"]))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the ranks are started before anything touches the GPU; this process never does.  A fresh default seed has to be
         # drawn HERE: every rank must name the same seed for case k
