@@ -285,6 +285,7 @@ def main():
         achieved = STATE_BYTES[precision] * rate / 1e9
         key = f"{precision}_n{args.n}_c{args.chains}_s{args.mc_steps}"
         traffic, traffic_raw, traffic_how = None, None, None
+        all_ops = with_inst = waiting = None
         valu_ops, src = VALU_OPS_ESTIMATE[precision], "estimate (no PMC record for these kernel sources)"
         f64_ops = VALU_F64_OPS_ESTIMATE.get(precision, 0.0)
         if pmc and key in pmc.get("records", {}):
@@ -295,6 +296,7 @@ def main():
                 src = "SQ_INSTS_VALU x 64 / updates, profiles/pmc_traffic.json (stamp = sha256 of the kernel sources)"
             if r.get("valu_f64_instructions_per_update_per_lane") is not None:
                 f64_ops = r["valu_f64_instructions_per_update_per_lane"]
+            all_ops, with_inst, waiting = r.get("instructions_per_update_per_lane"), r.get("wave_cycles_with_an_instruction"), r.get("wave_cycles_waiting")
         # an f64 op (v_fma/add/mul_f64 and the f64 transcendentals) issues at 16 lanes per clock and SIMD, everything else
         # (integer, select, f32, conversions: the generator, the address steering, the f32 Metropolis filter) at 32
         other_ops = max(0.0, valu_ops - f64_ops)
@@ -331,6 +333,10 @@ def main():
                      "ops_per_update": valu_ops, "f64_ops_per_update": f64_ops, "other_ops_per_update": other_ops,
                      "frac_note": "issue time: f64 ops priced at 16 lanes/clk/SIMD (3.93e13 lane-ops/s), all others at 32 (7.86e13)",
                      "waves_per_simd": waves_per_simd, "frac_one_wave_issue": one_wave_frac,
+                     "instructions_per_update": all_ops, "wave_cycles_with_an_instruction": with_inst, "wave_cycles_waiting": waiting,
+                     "wave_cycles_note": "PMC record (profiled passes of this command): VALU + SALU + LDS + VMEM instructions per update and "
+                                         "lane; the share of the waves' cycles in which one of their instructions was executing "
+                                         "(SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES) and in which they waited (SQ_WAIT_ANY / SQ_WAVE_CYCLES)",
                      "frac_one_wave_issue_note": "this launch seats at most one wave per SIMD, and one wave issues one vector "
                                                  "instruction per 4 cycles whatever its type: ops_per_update x 4 cycles x wave-steps/s "
                                                  "/ (1024 SIMDs x 2.4 GHz) -- the ceiling that applies to this ensemble size "

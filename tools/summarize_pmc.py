@@ -127,6 +127,13 @@ def main():
             "valu_wave_instructions_per_launch": mean["SQ_INSTS_VALU"],
             "valu_instructions_per_update_per_lane": mean["SQ_INSTS_VALU"] * 64 / a.updates,
             "valu_f64_instructions_per_update_per_lane": (f64_insts * 64 / a.updates) if f64_insts is not None else None,
+            # every counted instruction type (waitcnt, nop and branches have no counter): what a lone wave pays an issue slot for
+            "instructions_per_update_per_lane": sum(mean.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
+                                                                               "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")) * 64 / a.updates,
+            # share of the waves' cycles in which an instruction of theirs was executing / in which they sat in s_waitcnt
+            "wave_cycles_with_an_instruction": (mean["SQ_ACTIVE_INST_ANY"] / mean["SQ_WAVE_CYCLES"])
+            if "SQ_ACTIVE_INST_ANY" in mean and mean.get("SQ_WAVE_CYCLES") else None,
+            "wave_cycles_waiting": (mean["SQ_WAIT_ANY"] / mean["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in mean and mean.get("SQ_WAVE_CYCLES") else None,
             "kernel_ms_rocprof_trace": kern_ms,
         }
         json.dump(rec, open(path, "w"), indent=1)
