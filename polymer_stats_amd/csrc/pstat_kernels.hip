@@ -31,6 +31,9 @@
 #include "../../include/pstat.h"
 #include "pstat_math.h"
 
+#ifndef PSTAT_GM_DEPTH
+#define PSTAT_GM_DEPTH 2   // prefetch depth (steps) of the f64 non-interacting sweep with its cells in memory: 2 or 3
+#endif
 #ifndef PSTAT_GI_DEPTH
 #define PSTAT_GI_DEPTH 1   // prefetch depth (steps) of the f64 Ising sweep with its cells in memory
 #endif
@@ -170,7 +173,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // GM pipeline depth: 2 steps for the non-interacting step; the Ising step is ~2.5x as long and fetches three rows (the
   // monomer and its two neighbours), so one step ahead gives its loads the same time and a third of the registers
   constexpr bool GI = GM && EN == PSTAT_ISING;
-  constexpr int DEPTH = GI ? PSTAT_GI_DEPTH : 2;
+  constexpr int DEPTH = GI ? PSTAT_GI_DEPTH : PSTAT_GM_DEPTH;
   using Cell = typename std::conditional<Q, uint32_t, R2>::type;
   const int lanes = GM ? 64 : A.lanes;
   unsigned char *const cells = GM ? reinterpret_cast<unsigned char *>(S.work) + (size_t)blk * (size_t)A.n * 64 * sizeof(Cell) : smem;
@@ -284,14 +287,18 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   };
   // a fetched cell at its first use: its home, then the commits made after its load was issued (fw2 older, fw1 newer)
   auto resolve = [&](const RowG &r, const uint32_t idx, const uint32_t cell, const Cell &f1, const uint32_t at1,
-                     const Cell &f2, const uint32_t at2) __attribute__((always_inline)) -> Cell {
+                     const Cell &f2, const uint32_t at2, const Cell &f3, const uint32_t at3) __attribute__((always_inline)) -> Cell {
     if constexpr (GM) {
       typedef double v2dd __attribute__((ext_vector_type(2)));
       const v2dd gv = __builtin_bit_cast(v2dd, r.g);
       const bool inL = idx < nL;
       Cell a;
       a.x = inL ? r.l.x : gv.x; a.y = inL ? r.l.y : gv.y;
-      if constexpr (DEPTH == 2) {
+      if constexpr (DEPTH == 3) {
+        const bool s3 = at3 == cell;
+        a.x = s3 ? f3.x : a.x; a.y = s3 ? f3.y : a.y;
+      }
+      if constexpr (DEPTH >= 2) {
         const bool s2 = at2 == cell;
         a.x = s2 ? f2.x : a.x; a.y = s2 ? f2.y : a.y;
       }
@@ -337,13 +344,21 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // into it at its first use (fw1 = previous step, fw2 = the one before; ~0 = no such cell).
   Draw dC = dA;
   Row aC = aA;
-  Cell fw1_cell{}, fw2_cell{};
-  uint32_t fw1_at = ~0u, fw2_at = ~0u;
-  (void)dC; (void)aC; (void)fw1_cell; (void)fw2_cell; (void)fw1_at; (void)fw2_at;
-  if constexpr (GM && DEPTH == 2) {
+  Draw dD = dA;             // (a third step of depth, PSTAT_GM_DEPTH = 3: four sets, three forwarded commits)
+  Row aD = aA;
+  Cell fw1_cell{}, fw2_cell{}, fw3_cell{};
+  uint32_t fw1_at = ~0u, fw2_at = ~0u, fw3_at = ~0u;
+  (void)dC; (void)aC; (void)dD; (void)aD; (void)fw1_cell; (void)fw2_cell; (void)fw3_cell; (void)fw1_at; (void)fw2_at; (void)fw3_at;
+  if constexpr (GM && DEPTH >= 2) {
     if (remaining > 1) {
       dB = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes);
       aB = rdrow(dB);
+    }
+    if constexpr (DEPTH == 3) {
+      if (remaining > 2) {
+        dC = draw_step<RARE>(g, (uint32_t)n, flips, row_bytes, lane_bytes);
+        aC = rdrow(dC);
+      }
     }
   }
   R phistep3 = 3 * phistep, thstep3 = 3 * thstep;
@@ -413,11 +428,11 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       (void)aLo; (void)aHi;
       if constexpr (GI) {
         const bool hasLo = d.idx > 0, hasHi = d.idx + 1 < (uint32_t)n;
-        a0 = resolve(a0_.c, d.idx, d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at);
-        aLo = resolve(a0_.lo, hasLo ? d.idx - 1 : d.idx, hasLo ? d.cell - row_bytes : d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at);
-        aHi = resolve(a0_.hi, hasHi ? d.idx + 1 : d.idx, hasHi ? d.cell + row_bytes : d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at);
+        a0 = resolve(a0_.c, d.idx, d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at, fw3_cell, fw3_at);
+        aLo = resolve(a0_.lo, hasLo ? d.idx - 1 : d.idx, hasLo ? d.cell - row_bytes : d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at, fw3_cell, fw3_at);
+        aHi = resolve(a0_.hi, hasHi ? d.idx + 1 : d.idx, hasHi ? d.cell + row_bytes : d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at, fw3_cell, fw3_at);
       } else if constexpr (GM) {
-        a0 = resolve(a0_, d.idx, d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at);
+        a0 = resolve(a0_, d.idx, d.cell, fw1_cell, fw1_at, fw2_cell, fw2_at, fw3_cell, fw3_at);
       } else {
         a0 = a0_;
       }
@@ -652,6 +667,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       if constexpr (EN == PSTAT_ISING) nnan_seg += not_finite(dU) ? 1 : 0;
       if constexpr (GM) {
         // (a rejected step changed nothing in memory: it forwards nothing, so the trial angles need no select here)
+        fw3_cell = fw2_cell; fw3_at = fw2_at;
         fw2_cell = fw1_cell; fw2_at = fw1_at;
         fw1_cell.x = th1; fw1_cell.y = ph1; fw1_at = ok ? d.cell : ~0u;
       } else if (more) {  // forward the accepted angles into the prefetched row if it is the same monomer
@@ -690,7 +706,21 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       // exactly how many younger operations are in flight, or it ends up waiting for the previous step's STORE as well.
       // The main loop therefore prefetches unconditionally and the segment's last steps run in the tail.
       // (`more` of a step = a step two after it exists in this segment; the main loop covers only such steps)
-      if constexpr (DEPTH == 2) {
+      if constexpr (DEPTH == 3) {
+        const int lim = chunk < left - 3 ? chunk : left - 3;
+        for (; k + 4 <= lim; k += 4) {
+          one_step(dA, aA, dD, aD, true);
+          one_step(dB, aB, dA, aA, true);
+          one_step(dC, aC, dB, aB, true);
+          one_step(dD, aD, dC, aC, true);
+        }
+        for (; k < chunk; ++k) {
+          one_step(dA, aA, dD, aD, left - k > 3);
+          dA = dB; aA = aB;
+          dB = dC; aB = aC;
+          dC = dD; aC = aD;
+        }
+      } else if constexpr (DEPTH == 2) {
         const int lim = chunk < left - 2 ? chunk : left - 2;
         for (; k + 3 <= lim; k += 3) {
           one_step(dA, aA, dC, aC, true);
