@@ -1,12 +1,17 @@
 """Throughput floors on the GPU box: not a benchmark (bench.py is), a tripwire.  Each floor is about half of what the
 configuration measured on MI355X in rounds 2 and 3, so box-to-box differences cannot trip it, while the
 kind of accident that does happen -- a launch-shape chooser picking a bad lane count, a kernel falling back to a slow
-variant, state no longer where it should be -- costs more than that."""
+variant, state no longer where it should be -- costs more than that.
+
+Two tests per configuration, under two markers:
+  * `gpu`  -- test_kernel_variant: which kernel and launch shape pstat_create picked.  No clock is read, so a slow or shared
+              box cannot fail it; it runs inside the parity suite (`pytest -m gpu`).
+  * `perf` -- test_throughput_floor: the wall-clock floor.  NOT part of `-m gpu` (under `pytest -x` one slow box would stop the
+              run before the closed-form and oracle tests that sort after it); run it with `pytest -m perf` on the GPU box."""
 import time
 
 import pytest
 
-pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
@@ -60,6 +65,21 @@ CASES = [
 ]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,floor,steps,kernel,kw", CASES, ids=[c[0] for c in CASES])
+def test_kernel_variant(ps, name, floor, steps, kernel, kw):
+    """The fallback-variant tripwire without a clock: the kernel pstat_create picks for the configuration, that it has a
+    resident slot on every CU, and that a short launch of it completes."""
+    with ps.Ensemble(ps.default_params(**kw)) as e:
+        info = e.launch_info()
+        assert kernel in info.kernel.decode(), info.kernel.decode()
+        assert info.blocks_per_cu >= 1 and info.blocks >= 1 and 1 <= info.lanes_per_block <= 64
+        e.advance(64)
+        e.sync()
+        assert e.summary().steps_per_chain == 64
+
+
+@pytest.mark.perf
 @pytest.mark.parametrize("name,floor,steps,kernel,kw", CASES, ids=[c[0] for c in CASES])
 def test_throughput_floor(ps, name, floor, steps, kernel, kw):
     rate, info = _rate(ps, steps, **kw)
