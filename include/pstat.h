@@ -18,6 +18,18 @@
  *
  * One handle = `num_chains` independent Markov chains per case (chain-per-lane on the device), each
  * one statistically identical to one reference run with `--num-inits 1`; results are pooled.
+ *
+ * RESOLUTION OF THE UNIFORM DRAWS (ours; the reference draws Float64 uniforms with 52-53 random bits from an unseeded
+ * generator, mcmc_eap_chain.jl:277-280,287).  Every uniform here is made from 32-bit generator words:
+ *   * proposals  dphi = phi_step (2u - 1), dtheta = theta_step (2u - 1), u = (w >> 9) 2^-23: a lattice of step / 2^22
+ *     (symmetric, so detailed balance holds on it; the adapted step sizes are incommensurate, so chains are not confined
+ *     to one lattice), in every precision;
+ *   * the Metropolis eps (mcmc_eap_chain.jl:287, inc/acceptance.jl:29-39): `uniform_bits` below.  With 23 bits eps = 0
+ *     comes up once per 2^23 = 8.4e6 proposals and then ANY proposal of finite energy with exp(delta) > 0 is accepted, so
+ *     acceptance probabilities have a floor of 2^-23 = 1.2e-7 (tests/test_gpu_parity.py pins this on a cold, strongly
+ *     coupled chain).  With 53 bits -- the default of the f64 kernels -- the floor is 2^-53 = 1.1e-16, the reference's own;
+ *   * the clustering main's link and skip draws (inc/eap_chain.jl:276,286,303) and the re-initialisation draw
+ *     (mcmc_eap_chain.jl:357): 23 bits, `u <= p`.
  */
 #ifndef PSTAT_H
 #define PSTAT_H
@@ -29,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PSTAT_ABI_VERSION 5
+#define PSTAT_ABI_VERSION 6
 
 typedef enum pstat_status {
   PSTAT_OK = 0,
@@ -103,7 +115,12 @@ typedef struct pstat_params {
   double x0_phi, x0_theta;       /* --x0 "[phi; theta]"                                       */
   double dx0_phi, dx0_theta;     /* --dx0                                                     */
   int32_t use_x0;                /* start from x0 + Uniform(0, dx0) instead of uniform angles */
-  int32_t reserved;              /* must be 0                                                 */
+  int32_t uniform_bits;          /* random bits of the Metropolis eps: 0 = the precision's default (53 for PSTAT_F64, 23
+                                  * for PSTAT_F32 / PSTAT_Q16, whose comparison runs in a 24-bit mantissa), 23, or 53 (f64
+                                  * only).  Under 53 eps = (w_eps 2^21 + lo) 2^-53, lo = the low 9 bits of the step's dtheta
+                                  * word, the low 9 of its dphi word and the low 3 of its index word -- bits no proposal
+                                  * uses; no extra draw, so the two settings consume the same stream and differ only in
+                                  * decisions that fall inside [u, u + 2^-23).  23 reproduces ABI 5's trajectories.      */
   double cutoff_radius;          /* --cutoff-radius, monomer lengths (PSTAT_CUTOFF; per case)  */
 } pstat_params;
 
@@ -175,7 +192,10 @@ void pstat_default_params(pstat_params *p);
  * (mcmc_eap_chain.jl:175-176,242-255; inc/eap_chain.jl:60-135): draws phi~U(0,2pi), theta~U(0,pi)
  * for every chain on the device, derives r, p, U, zeroes the running sums.
  * `cases`/`ncases`: ncases >= 1 parameter sets that differ only in the physics scalars
- * (E0,K1,K2,mu,kT,Fz,Fx,b) -- a sweep grid run in one launch; every case gets num_chains chains.
+ * (E0,K1,K2,mu,kT,Fz,Fx,b; bend_mod, bend_angle, cluster_prob, cutoff_radius; seed, chain_id0) -- a sweep grid run in
+ * one launch; every case gets num_chains chains.  Chains of several cases share a wavefront when a case has fewer
+ * chains than a wave has lanes and that shortens the launch (pstat_launch_info.packed_cases); a chain's trajectory
+ * depends on its (seed, chain id) and its case's options only, never on what else is in the handle.
  * `stream`: a hipStream_t to launch on (e.g. torch's current stream) or NULL for the handle's own. */
 int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_handle **out);
 void pstat_destroy(pstat_handle *h);
@@ -267,7 +287,15 @@ int pstat_restart_from_x0(pstat_handle *h, const double *x0, int64_t len, double
 int pstat_chain_extras(pstat_handle *h, int64_t chain, double extra_sums[2], double extra_now[2]);
 
 /* Checkpoint / resume of the full device state (angles, generators, step sizes, counters, running
- * sums).  Call with buf == NULL to get the size.  The reference has no equivalent. */
+ * sums) and of every case's CURRENT kT (a rung of the burn-in ladder set by pstat_scale_kT / pstat_set_kT is
+ * restored with the image).  pstat_checkpoint: call with buf == NULL to get the size in *bytes; a buffer that is too
+ * small fails with PSTAT_ERR_TOO_SMALL and the required size written back.  pstat_restore continues exactly the run
+ * the image was taken from, on a handle created with the same options: the image's header (format 4) names the ABI
+ * version, n, the chain and case counts, precision, chain / energy type, generator, move set, umbrella, do-flips,
+ * uniform_bits, case 0's seed and first chain id, and a fingerprint of all cases' physics scalars (other than the
+ * current kT), seeds, chain ids, num_chains and the proposal / adaptation options; any mismatch, a foreign or
+ * truncated buffer fails with PSTAT_ERR_BAD_CHECKPOINT and leaves the handle untouched.  The reference has no
+ * equivalent. */
 int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes);
 int pstat_restore(pstat_handle *h, const void *buf, size_t bytes);
 
@@ -281,6 +309,10 @@ typedef struct pstat_launch_info {
   int64_t blocks;
   int32_t blocks_per_cu;
   int32_t num_cus;
+  int32_t packed_cases;     /* 1: a workgroup holds `lanes_per_block` consecutive chains whichever cases they belong to (picked
+                             * by pstat_create when cases have few chains each: the reference's sweeps run 1-25 per case,
+                             * run/K1_E0-kT-phase.jl:19-45); 0: workgroups never straddle a case                          */
+  int32_t reserved;
 } pstat_launch_info;
 int pstat_launch_info_get(pstat_handle *h, pstat_launch_info *out);
 

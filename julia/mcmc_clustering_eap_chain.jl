@@ -25,7 +25,7 @@ struct PstatParams
   rng::Int32; move_set::Int32
   bend_mod::Cdouble; bend_angle::Cdouble; cluster_prob::Cdouble
   x0_phi::Cdouble; x0_theta::Cdouble; dx0_phi::Cdouble; dx0_theta::Cdouble
-  use_x0::Int32; reserved::Int32
+  use_x0::Int32; uniform_bits::Int32      # 0 = the precision's default (53 random bits in the Metropolis eps for f64)
   cutoff_radius::Cdouble
 end
 

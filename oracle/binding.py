@@ -36,7 +36,8 @@ class EapParams(C.Structure):
                 ("bend_mod", "bend_angle", "cluster_prob", "x0_phi", "x0_theta", "dx0_phi", "dx0_theta")] + \
                [("burn_sched", C.c_double * 8), ("burn_in", C.c_int64),
                 ("burn_nsched", C.c_int32), ("use_x0", C.c_int32), ("cutoff_radius", C.c_double),
-                ("x0_vec", C.POINTER(C.c_double)), ("x0_len", C.c_int64)]
+                ("x0_vec", C.POINTER(C.c_double)), ("x0_len", C.c_int64),
+                ("uniform_bits", C.c_int32), ("pad_", C.c_int32)]
 
 
 class EapResult(C.Structure):
@@ -81,6 +82,10 @@ def lib():
         L.eap_mwc64x_skip.restype = C.c_uint64
         L.eap_u01.argtypes = [C.c_uint32]
         L.eap_u01.restype = C.c_double
+        L.eap_eps.argtypes = [C.c_int] + [C.c_uint32] * 4
+        L.eap_eps.restype = C.c_double
+        L.eap_find_eps23_zero.argtypes = [C.POINTER(EapParams), C.c_uint64, C.c_int64, C.POINTER(C.c_int64), C.c_int64]
+        L.eap_find_eps23_zero.restype = C.c_int64
         for f in (L.eap_run_faithful, L.eap_run_fast, L.eap_run_cluster):
             f.argtypes = [C.POINTER(EapParams), C.c_uint64, C.POINTER(EapResult), C.POINTER(EapTrace)]
             f.restype = C.c_int
@@ -105,7 +110,8 @@ def make_params(**kw) -> EapParams:
              seed=0, chain_type=DIELECTRIC, energy_type=NONINTERACTING,
              do_flips=0, force_init=0, umbrella=0, rng=RNG_MWC64X,
              bend_mod=0.0, bend_angle=0.0, cluster_prob=1.0, x0_phi=0.0, x0_theta=0.0,
-             dx0_phi=2 * np.pi, dx0_theta=0.1, burn_in=0, burn_nsched=0, use_x0=0, cutoff_radius=7.5)
+             dx0_phi=2 * np.pi, dx0_theta=0.1, burn_in=0, burn_nsched=0, use_x0=0, cutoff_radius=7.5,
+             uniform_bits=0)      # 0 | 53: the Metropolis eps has 53 random bits (the f64 kernels' default); 23: the f32 one
     sched = list(kw.pop("burn_sched", []))
     x0_vec = kw.pop("x0_vec", None)
     unknown = set(kw) - set(d)
@@ -210,6 +216,13 @@ def run_many(params: EapParams, id0: int, nchains: int, nthreads: int = 1, mode:
     if extras:
         return sums, norm, nacc, np.array([a.extra_sum[:] for a in arr])
     return sums, norm, nacc
+
+
+def find_eps23_zero(params: EapParams, chain_id: int, nsteps: int, max_hits: int = 64):
+    """0-based steps of the chain (fixed-force main, no flips, first init) whose Metropolis word has 23 leading zero bits."""
+    hits = (C.c_int64 * max_hits)()
+    k = lib().eap_find_eps23_zero(C.byref(params), chain_id, nsteps, hits, max_hits)
+    return [int(hits[i]) for i in range(min(k, max_hits))]
 
 
 def philox(ctr, key):

@@ -21,6 +21,8 @@
  *                          M = A*2^32 - 1 (skip-ahead: state * A^(k 2^40) mod M)
  *     EAP_RNG_XOSHIRO128PP xoshiro128++ seeded with Philox4x32-10(key = seed, ctr = (chain_lo, chain_hi, 0x5eed, 0))
  *   u(w)    = (w >> 9) * 2^-23   (23 bits: exactly the f32 mantissa trick the kernels use)
+ *   eps     : the Metropolis draw.  uniform_bits = 23: u(w_eps).  uniform_bits = 0 | 53 (default): 53 random bits like the
+ *             reference's rand(), from w_eps and the bits of the step's other words that nothing else uses -- eap_eps()
  *   init    : phi_i = 2pi*u  for i = 1..n, then theta_i = pi*u for i = 1..n   (eap_chain.jl:6-7,61-62)
  *   step    : idx = mulhi32(w, n); dphi = phi_step*(2u-1); [flip bit = w>>31 if --do-flips];
  *             dtheta = theta_step*(2u-1); eps = u                              (mcmc_eap_chain.jl:277-287)
@@ -122,15 +124,20 @@ uint32_t eap_mwc64x_next(uint32_t s[4]) {
 
 double eap_u01(uint32_t w) { return (double)(w >> 9) * (1.0 / 8388608.0); }
 
+double eap_eps(int uniform_bits, uint32_t w_eps, uint32_t w_idx, uint32_t w_phi, uint32_t w_th) {
+  if (uniform_bits == 23) return eap_u01(w_eps);
+  const uint64_t lo = ((uint64_t)(w_th & 511u) << 12) | ((uint64_t)(w_phi & 511u) << 3) | (uint64_t)(w_idx & 7u);
+  return (double)(((uint64_t)w_eps << 21) | lo) * 0x1p-53;      /* < 2^53: exact */
+}
+
 /* generator state: s[0..3] + the kind in s[4] (kept beside the state so every draw site stays a
  * one-liner) */
 static inline uint32_t draw_w(uint32_t s[5]) {
   return s[4] == EAP_RNG_XOSHIRO128PP ? eap_xoshiro128pp_next(s) : eap_mwc64x_next(s);
 }
 static inline double draw_u(uint32_t s[5]) { return eap_u01(draw_w(s)); }
-static inline int64_t draw_idx(uint32_t s[5], int64_t n) {
-  return (int64_t)(((uint64_t)draw_w(s) * (uint64_t)n) >> 32);
-}
+static inline int64_t idx_of(uint32_t w, int64_t n) { return (int64_t)(((uint64_t)w * (uint64_t)n) >> 32); }
+static inline double sym_of(uint32_t w) { return 2.0 * eap_u01(w) - 1.0; }
 static void seed_chain(const eap_params *P, uint64_t chain_id, uint32_t s[5]) {
   s[4] = (uint32_t)P->rng;
   if (P->rng == EAP_RNG_XOSHIRO128PP) eap_rng_seed(P->seed, chain_id, s);
@@ -422,6 +429,7 @@ static void adapt(const eap_params *P, int64_t step, double *phistep, double *th
 
 static int check_params(const eap_params *P) {
   if (P->n < 1 || P->num_steps < 0 || P->num_inits < 1) return -1;
+  if (P->uniform_bits != 0 && P->uniform_bits != 23 && P->uniform_bits != 53) return -1;
   if (P->chain_type != EAP_DIELECTRIC && P->chain_type != EAP_POLAR) return -1;
   if (P->energy_type < 0 || P->energy_type > EAP_CUTOFF) return -1;
   if (P->rng != EAP_RNG_MWC64X && P->rng != EAP_RNG_XOSHIRO128PP) return -1;
@@ -451,15 +459,17 @@ int eap_run_faithful(const eap_params *P, uint64_t chain_id, eap_result *out, ea
 
   for (int64_t init = 1; init <= P->num_inits; ++init) {        /* :266 */
     for (int64_t step = 1; step <= P->num_steps; ++step, ++t) { /* :276 */
-      int64_t idx = draw_idx(rng, P->n);                        /* :277 */
-      double dphi = phistep * (2.0 * draw_u(rng) - 1.0);        /* :278 */
+      const uint32_t w_idx = draw_w(rng), w_phi = draw_w(rng);
+      int64_t idx = idx_of(w_idx, P->n);                        /* :277 */
+      double dphi = phistep * sym_of(w_phi);                    /* :278 */
       double flip = 0.0;
       if (P->do_flips && (draw_w(rng) >> 31))                   /* :279 */
         flip = M_PI - 2 * cur.th[idx];
-      double dth = flip + thstep * (2.0 * draw_u(rng) - 1.0);   /* :280 */
+      const uint32_t w_th = draw_w(rng);
+      double dth = flip + thstep * sym_of(w_th);                /* :280 */
       chain_copy(&trial, &cur);                                 /* :281 */
       chain_move(P, &trial, idx, dphi, dth);                    /* :283 */
-      double eps = draw_u(rng);                                 /* :287 */
+      double eps = eap_eps(P->uniform_bits, draw_w(rng), w_idx, w_phi, w_th);   /* :287 */
       /* Metropolis functor, acceptance.jl:29-39 */
       double logpi = -trial.U / P->kT + trial.Omega + (wf.on ? weight_eval(&wf, sum_us(&trial)) : 1.0);
       int ok = (logpi >= logpi_prev) || (eps < exp(logpi - logpi_prev));
@@ -573,13 +583,14 @@ static void cluster_stage(const eap_params *P, int64_t nsteps, uint32_t rng[5], 
   extra[0] = extra[1] = 0.0;
   int64_t nacc = 0, natt = 0, nacc_total = 0;
   for (int64_t step = 1; step <= nsteps; ++step, ++*t) {          /* :268 */
-    int64_t idx = draw_idx(rng, P->n);
-    double dphi = phistep * (2.0 * draw_u(rng) - 1.0);
-    double dth = thstep * (2.0 * draw_u(rng) - 1.0);
+    const uint32_t w_idx = draw_w(rng), w_phi = draw_w(rng), w_th = draw_w(rng);
+    int64_t idx = idx_of(w_idx, P->n);
+    double dphi = phistep * sym_of(w_phi);
+    double dth = thstep * sym_of(w_th);
     chain_copy(trial, cur);
     chain_move(P, trial, idx, dphi, dth);                         /* :272 */
     double alpha = cluster_flip(P, rng, trial, idx);              /* :273 */
-    double eps = draw_u(rng);
+    double eps = eap_eps(P->uniform_bits, draw_w(rng), w_idx, w_phi, w_th);
     /* acceptance.jl:29-39 with alpha; the cached value keeps the log(alpha) of the accepted move */
     double logpi = -trial->U / P->kT + trial->Omega + (wf.on ? weight_eval(&wf, sum_us(trial)) : 1.0) + log(alpha);
     int ok = (logpi >= logpi_prev) || (eps < exp(logpi - logpi_prev));
@@ -750,12 +761,14 @@ int eap_run_fast(const eap_params *P, uint64_t chain_id, eap_result *out, eap_tr
 
   for (int64_t init = 1; init <= P->num_inits; ++init) {
     for (int64_t step = 1; step <= P->num_steps; ++step, ++t) {
-      int64_t idx = draw_idx(rng, P->n);
-      double dphi = phistep * (2.0 * draw_u(rng) - 1.0);
+      const uint32_t w_idx = draw_w(rng), w_phi = draw_w(rng);
+      int64_t idx = idx_of(w_idx, P->n);
+      double dphi = phistep * sym_of(w_phi);
       double flip = 0.0;
       if (P->do_flips && (draw_w(rng) >> 31)) flip = M_PI - 2 * c.th[idx];
-      double dth = flip + thstep * (2.0 * draw_u(rng) - 1.0);
-      double eps = draw_u(rng);
+      const uint32_t w_th = draw_w(rng);
+      double dth = flip + thstep * sym_of(w_th);
+      double eps = eap_eps(P->uniform_bits, draw_w(rng), w_idx, w_phi, w_th);
 
       double phi1 = c.phi[idx] + dphi;
       double th1 = fmin(M_PI, fmax(0.0, c.th[idx] + dth));
@@ -852,6 +865,21 @@ double eap_chain_energy(const eap_params *P, const double *phi, const double *th
   double U = c.U;
   chain_free(&c);
   return U;
+}
+
+int64_t eap_find_eps23_zero(const eap_params *P, uint64_t chain_id, int64_t nsteps, int64_t *hits, int64_t max_hits) {
+  uint32_t rng[5];
+  seed_chain(P, chain_id, rng);
+  for (int64_t i = 0; i < 2 * P->n; ++i) (void)draw_w(rng);       /* EAPChain(pargs): n phi draws, n theta draws */
+  int64_t found = 0;
+  for (int64_t s = 0; s < nsteps; ++s) {
+    (void)draw_w(rng); (void)draw_w(rng); (void)draw_w(rng);      /* idx, dphi, dtheta */
+    if ((draw_w(rng) >> 9) == 0u) {
+      if (found < max_hits) hits[found] = s;
+      ++found;
+    }
+  }
+  return found;
 }
 
 typedef struct {

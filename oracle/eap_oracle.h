@@ -58,6 +58,9 @@ typedef struct eap_params {
   double cutoff_radius;                 /* --cutoff-radius, in monomer lengths (:48-51; x mlen at inc/eap_chain.jl:102) */
   const double *x0_vec;                 /* --x0 of length 2n, [phi1, theta1, phi2, theta2, ...] (inc/eap_chain.jl:73-75); */
   int64_t x0_len;                       /*   used when use_x0 != 0 and x0_len == 2n, else x0_phi/x0_theta */
+  int32_t uniform_bits;                 /* random bits of the Metropolis eps: 0 or 53 = 53 (the reference's rand() is a Float64
+                                           with 52-53 random bits, mcmc_eap_chain.jl:287), 23 = (w >> 9) 2^-23; see eap_eps() */
+  int32_t pad_;
 } eap_params;
 
 /* Index order = the rolling.csv columns after "step" (mcmc_eap_chain.jl:259). */
@@ -100,6 +103,13 @@ void eap_mwc64x_seed(uint64_t seed, uint64_t chain_id, uint32_t s[4]); /* s[0] =
 uint32_t eap_mwc64x_next(uint32_t s[4]);
 uint64_t eap_mwc64x_skip(uint64_t state, uint64_t nsteps);             /* state = c*2^32 + x */
 double eap_u01(uint32_t w);                       /* (w>>9) * 2^-23 in [0,1) */
+/* the Metropolis eps of one step from that step's words: w_eps, and -- under 53 bits -- the bits of the index, dphi and
+ * dtheta words that nothing else uses: (w_eps 2^21 + (w_th & 511) 2^12 + (w_phi & 511) 2^3 + (w_idx & 7)) 2^-53 */
+double eap_eps(int uniform_bits, uint32_t w_eps, uint32_t w_idx, uint32_t w_phi, uint32_t w_th);
+/* Stream scan for tests: the 0-based steps s < nsteps of chain `chain_id` (fixed-force main, no --do-flips, one init: word
+ * 2n + 4s + 3 of the chain's stream is that step's w_eps) whose eps has all 23 leading bits zero; returns how many were found
+ * (at most `max_hits` are written). */
+int64_t eap_find_eps23_zero(const eap_params *P, uint64_t chain_id, int64_t nsteps, int64_t *hits, int64_t max_hits);
 
 /* --- the two restatements --- */
 /* Literal algorithm: trial = deep copy, full prefix sum, full energy recompute,

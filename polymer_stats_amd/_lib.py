@@ -30,7 +30,7 @@ SYMBOLS = [
     "pstat_summary_get", "pstat_summary_from_reduction", "pstat_chain_state", "pstat_chain_extras", "pstat_restart_from_x0",
     "pstat_checkpoint", "pstat_restore", "pstat_launch_info_get", "pstat_chain_means",
 ]
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class PstatError(RuntimeError):
@@ -49,7 +49,7 @@ class Params(C.Structure):
                 ("chain_type", "energy_type", "do_flips", "umbrella", "precision", "device", "rng", "move_set")] + \
                [(k, C.c_double) for k in
                 ("bend_mod", "bend_angle", "cluster_prob", "x0_phi", "x0_theta", "dx0_phi", "dx0_theta")] + \
-               [("use_x0", C.c_int32), ("reserved", C.c_int32), ("cutoff_radius", C.c_double)]
+               [("use_x0", C.c_int32), ("uniform_bits", C.c_int32), ("cutoff_radius", C.c_double)]
 
 
 class Summary(C.Structure):
@@ -64,7 +64,7 @@ class Summary(C.Structure):
 class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("lds_bytes", C.c_int32), ("threads_per_block", C.c_int32),
                 ("lanes_per_block", C.c_int32), ("blocks", C.c_int64), ("blocks_per_cu", C.c_int32),
-                ("num_cus", C.c_int32)]
+                ("num_cus", C.c_int32), ("packed_cases", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None

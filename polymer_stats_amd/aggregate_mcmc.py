@@ -61,6 +61,15 @@ def aggregate(outfile: str, indir: str, pattern: str, chain: str, kappaflag: boo
         heads.append("kappa")
     files = sorted(os.path.join(indir, f) for f in os.listdir(indir) if fnmatch.fnmatchcase(f, pattern))
     rows = [(f, name_fields(f, runflag), out_values(f)) for f in files]
+    # The reference hcat's whatever the file name holds under the fixed header (scripts/aggregate_mcmc.jl:54,67-74): a name
+    # with fewer or more tokens than the header has input columns shifts every value under the wrong heading, silently.
+    # Here that is an error: name the files with all of the header's keys (run_sweep.py --name E0,K1,K2,kT,Fz,Fx,n,b[,kappa][,run:raw]).
+    for f, fields, _ in rows:
+        if len(fields) != len(heads):
+            print(f"{os.path.basename(f)}: the file name holds {len(fields)} input field(s) but the header of a {chain} "
+                  f"aggregate has {len(heads)} ({','.join(heads)}{' + a run token' if runflag else ''}): columns would be "
+                  "misaligned", file=sys.stderr)
+            return 1
     cols = OUT_3D if not rows or len(rows[0][2]) == len(OUT_3D) else [c for c in OUT_3D if c not in ("Ealign", "psi")]
     with open(outfile, "w") as out:
         out.write(",".join(heads + cols) + "\n")

@@ -37,7 +37,7 @@ int fail(int code, const char *fmt, ...) {
       return fail(PSTAT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));          \
   } while (0)
 
-constexpr uint64_t CKPT_MAGIC = 0x5053544154434b33ull;  // "PSTATCK3" (v3: + the non-finite-energy rejection counters)
+constexpr uint64_t CKPT_MAGIC = 0x5053544154434b34ull;  // "PSTATCK4" (v4: the header identifies the handle it was taken from)
 
 struct Buffer {
   void *ptr = nullptr;
@@ -103,7 +103,10 @@ int validate(const pstat_params *c, int ncases) {
     return fail(PSTAT_ERR_UNSUPPORTED, "the lattice state (PSTAT_Q16) is not implemented for energy-type 'interacting'");
   if (b.rng != PSTAT_RNG_MWC64X && b.rng != PSTAT_RNG_XOSHIRO128PP)
     return fail(PSTAT_ERR_INVALID_ARG, "rng must be PSTAT_RNG_MWC64X or PSTAT_RNG_XOSHIRO128PP");
-  if (b.reserved != 0) return fail(PSTAT_ERR_INVALID_ARG, "reserved field must be 0");
+  if (b.uniform_bits != 0 && b.uniform_bits != 23 && b.uniform_bits != 53)
+    return fail(PSTAT_ERR_INVALID_ARG, "uniform_bits must be 0 (the precision's default), 23 or 53");
+  if (b.uniform_bits == 53 && b.precision != PSTAT_F64)
+    return fail(PSTAT_ERR_INVALID_ARG, "uniform_bits = 53 needs PSTAT_F64: the f32 / q16 arithmetic compares eps in a 24-bit mantissa");
   if (b.rng == PSTAT_RNG_MWC64X)
     for (int i = 0; i < ncases; ++i)
       if (c[i].chain_id0 > PSTAT_MWC64X_MAX_CHAINS || (uint64_t)b.num_chains > PSTAT_MWC64X_MAX_CHAINS - c[i].chain_id0)
@@ -143,7 +146,7 @@ int validate(const pstat_params *c, int ncases) {
         p.theta_step != b.theta_step || p.adj_lb != b.adj_lb || p.adj_ub != b.adj_ub ||
         p.adj_scale != b.adj_scale || p.steps_per_adjust != b.steps_per_adjust || p.move_set != b.move_set ||
         p.use_x0 != b.use_x0 || p.x0_phi != b.x0_phi || p.x0_theta != b.x0_theta || p.dx0_phi != b.dx0_phi ||
-        p.dx0_theta != b.dx0_theta)
+        p.dx0_theta != b.dx0_theta || p.uniform_bits != b.uniform_bits)
       return fail(PSTAT_ERR_INVALID_ARG, "case %d differs from case 0 in a non-physics field", i);
   }
   return PSTAT_OK;
@@ -232,7 +235,7 @@ void pstat_default_params(pstat_params *p) {
   p->chain_type = PSTAT_DIELECTRIC; p->energy_type = PSTAT_NONINTERACTING;
   p->do_flips = 0; p->umbrella = 0;
   p->precision = PSTAT_F64; p->device = 0;   // the reference's Float64 (inc/types.jl); PSTAT_F32 is the opt-in fast path
-  p->rng = PSTAT_RNG_MWC64X; p->reserved = 0;
+  p->rng = PSTAT_RNG_MWC64X; p->uniform_bits = 0;   // 0 = the precision's default: 53 random bits in eps for f64, 23 for f32 / q16
   // mcmc_clustering_eap_chain.jl:36-43,87-90,142-148 (only read when move_set = PSTAT_MOVES_CLUSTER / use_x0)
   p->move_set = PSTAT_MOVES_SINGLE;
   p->bend_mod = 0.0; p->bend_angle = 0.0; p->cluster_prob = 0.5;
@@ -280,23 +283,21 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   A.n = h->base.n;
   A.chains_per_case = h->base.num_chains;
   A.blocks_per_case = (h->base.num_chains + lanes - 1) / lanes;
+  A.nblocks = A.blocks_per_case * ncases;
   A.nsteps = 0; A.step0 = 0;
   A.steps_per_adjust = h->base.steps_per_adjust;
   A.adj_lb = h->base.adj_lb; A.adj_ub = h->base.adj_ub; A.adj_scale = h->base.adj_scale;
   A.lanes = lanes;
   A.adaptive = (h->base.adj_scale != 1.0 && h->base.steps_per_adjust > 0) ? 1 : 0;  // mcmc_eap_chain.jl:302
   A.ncases = ncases; A.seg_len = 0; A.nseg = 1; A.max_spins = 1 << 22;
-  A.lds_rows = 0; A.pad_ = 0;
+  A.lds_rows = 0; A.packed = 0; A.pad_ = 0;
+  A.wide_eps = (h->base.precision == PSTAT_F64 && h->base.uniform_bits != 23) ? 1 : 0;
   const bool cluster_gm = h->cfg.state_global && h->cfg.move_set == PSTAT_MOVES_CLUSTER;   // pstat_cluster_gm.hip
   if (h->cfg.state_global && !cluster_gm) {   // a quarter of a CU's LDS per wave: four resident waves, 64 lanes x 16 B per row
     int rows = 160 * 1024 / 4 / (64 * 16) - 1;   // one row of the quarter is the trash row of run_segment
     const char *e = getenv("PSTAT_F64_LDS_ROWS");
     if (e && atoi(e) >= 0 && atoi(e) <= rows) rows = atoi(e);
     A.lds_rows = (int32_t)(h->base.n < rows ? h->base.n : rows);
-  }
-  if ((int64_t)A.blocks_per_case * ncases > 0x7fffffffLL) {
-    delete h;
-    return fail(PSTAT_ERR_INVALID_ARG, "too many chains for one launch");
   }
 
 #define CREATE_TRY(expr)            \
@@ -314,76 +315,103 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   } while (0)
 
   CREATE_HIP(hipSetDevice(h->device));
-  if (!inter && !h->cfg.state_global) {
-    // Chains per workgroup (active lanes of its single wave).  State lives in LDS, so a CU holds at
-    // most 160 KiB / (bytes per chain) chains; pick the lane count that minimises the makespan
-    // max(1, workgroups / resident slots) of one launch -- e.g. f32, n = 100: 51 lanes x 4
-    // workgroups per CU (204 chains, all four SIMDs) instead of 64 x 3 (192 chains, three SIMDs).
+  if (!inter) {
+    // ---- launch shape of the chain-per-lane kernels: active lanes per workgroup (one wave) and what a workgroup holds.
+    // `shape(packed)` prices the best lane count of one block layout with the makespan model of its kernel family;
+    // packed blocks (run_job_queue<true>: a block holds `lanes` consecutive global chains, whichever cases they belong
+    // to) are taken when they shorten the launch by more than 5 % -- an ensemble of 2 730 cases x 16 chains is 683 full
+    // waves instead of 2 730 quarter-filled ones.  Otherwise blocks stay inside a case and its scalars in SGPRs.
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, h->device));
-    int best = lanes;
-    double best_cost = 1e300;
+    const int64_t per_case = h->base.num_chains, total = per_case * ncases;
     const char *le = getenv("PSTAT_LANES");
-    bool lds_starved = false;     // full waves: fewer than one per SIMD fit a CU's LDS
-    {
-      int lds0 = 0, bpc0 = 0;
-      lds_starved = kernel_info(h->cfg, h->args, &lds0, &bpc0, nullptr) == hipSuccess && bpc0 < 4;
-    }
-    for (int cand = lanes; cand >= 8; --cand) {
-      if (le && atoi(le) >= 1 && atoi(le) <= lanes && cand != atoi(le)) continue;
-      SweepArgs probe = h->args;
-      probe.lanes = cand;
-      int lds = 0, bpc = 0;
-      if (kernel_info(h->cfg, probe, &lds, &bpc, nullptr) != hipSuccess || bpc < 1) continue;
-      const double slots = (double)bpc * prop.multiProcessorCount;
-      const double wgs = (double)ncases * (double)((h->base.num_chains + cand - 1) / cand);
-      double cost = wgs / slots;
-      if (cost < 1.0) cost = 1.0;
-      cost *= 1.0 + 1e-4 * (64 - cand);   // ties: prefer fuller waves
-      if (h->cfg.move_set == PSTAT_MOVES_CLUSTER && lds_starved) {
-        // (only when LDS seats fewer than four FULL waves per CU.)  The cluster step runs a wave for as long as its
-        // LONGEST cluster, so a wave of fewer lanes finishes its steps sooner (~ log of the lane count), and more,
-        // emptier waves also put the idle SIMDs to work.  Measured, n = 100, f64 (LDS seats 102 chains per CU): 4 x 25 lanes
-        // 4.08e9 proposals/s against 2 x 51 lanes 3.61e9 (non-interacting; Ising 5.70e9 / 5.57e9).  Sharing a SIMD
-        // between waves costs more than it gains here (f32: 4 x 51 lanes 1.77e10, 8 x 25 lanes 1.52e10).
-        const double waves_per_simd = bpc / 4.0;
-        cost *= 1.0 + 0.1 * std::log2(cand / 16.0);
-        if (waves_per_simd > 1.0) cost *= 1.0 + 0.25 * (waves_per_simd - 1.0);
+    struct Shape { int lanes; int64_t nblocks; double cost; };
+    auto shape = [&](const bool packed) -> Shape {
+      LaunchCfg cfg = h->cfg;
+      cfg.packed = packed ? 1 : 0;
+      auto wgs_of = [&](const int cand) -> int64_t {
+        return packed ? (total + cand - 1) / cand : (int64_t)ncases * ((per_case + cand - 1) / cand);
+      };
+      Shape best{lanes, wgs_of(lanes), 1e300};
+      if (h->cfg.state_global && !cluster_gm) {   // f64 sweep with its cells in memory: 64 lanes on every SIMD
+        int lds0 = 0, bpc = 0;
+        if (kernel_info(cfg, h->args, &lds0, &bpc, nullptr) != hipSuccess || bpc < 1) bpc = 4;
+        double cost = (double)best.nblocks / ((double)bpc * prop.multiProcessorCount);
+        best.cost = cost < 1.0 ? 1.0 : cost;
+        return best;
       }
-      if (cost < best_cost) { best_cost = cost; best = cand; }
+      if (cluster_gm) {
+        // Chains in device memory: nothing limits a wave to fewer than 64 lanes, but an ensemble of fewer waves than the
+        // chip has SIMDs (a phase scan: 546 grid points x 64 chains) runs faster as more, emptier waves -- they fill the
+        // idle SIMDs, and a wave's step lasts as long as its LONGEST cluster, which grows like the logarithm of its lanes.
+        int lds0 = 0, bpc = 0;
+        if (kernel_info(cfg, h->args, &lds0, &bpc, nullptr) != hipSuccess || bpc < 1) bpc = 1;
+        const double slots = (double)bpc * prop.multiProcessorCount;
+        for (int cand = 64; cand >= 16; cand >>= 1) {
+          if (le && atoi(le) >= 1 && atoi(le) <= 64 && cand != atoi(le)) continue;
+          double cost = (double)wgs_of(cand) / slots;
+          if (cost < 1.0) cost = 1.0;
+          cost *= 1.0 + 0.1 * std::log2(cand / 16.0);
+          if (cost < best.cost) best = Shape{cand, wgs_of(cand), cost};
+        }
+        return best;
+      }
+      // State in LDS: a CU holds at most 160 KiB / (bytes per chain) chains; pick the lane count that minimises the
+      // makespan max(1, workgroups / resident slots) of one launch -- e.g. f32, n = 100: 51 lanes x 4 workgroups per CU
+      // (204 chains, all four SIMDs) instead of 64 x 3 (192 chains, three SIMDs).
+      bool lds_starved = false;     // full waves: fewer than one per SIMD fit a CU's LDS
+      {
+        int lds0 = 0, bpc0 = 0;
+        lds_starved = kernel_info(cfg, h->args, &lds0, &bpc0, nullptr) == hipSuccess && bpc0 < 4;
+      }
+      for (int cand = lanes; cand >= 8; --cand) {
+        if (le && atoi(le) >= 1 && atoi(le) <= lanes && cand != atoi(le)) continue;
+        SweepArgs probe = h->args;
+        probe.lanes = cand;
+        int lds = 0, bpc = 0;
+        if (kernel_info(cfg, probe, &lds, &bpc, nullptr) != hipSuccess || bpc < 1) continue;
+        const double slots = (double)bpc * prop.multiProcessorCount;
+        double cost = (double)wgs_of(cand) / slots;
+        if (cost < 1.0) cost = 1.0;
+        cost *= 1.0 + 1e-4 * (64 - cand);   // ties: prefer fuller waves
+        if (h->cfg.move_set == PSTAT_MOVES_CLUSTER && lds_starved) {
+          // (only when LDS seats fewer than four FULL waves per CU.)  The cluster step runs a wave for as long as its
+          // LONGEST cluster, so a wave of fewer lanes finishes its steps sooner (~ log of the lane count), and more,
+          // emptier waves also put the idle SIMDs to work.  Measured, n = 100, f64 (LDS seats 102 chains per CU): 4 x 25 lanes
+          // 4.08e9 proposals/s against 2 x 51 lanes 3.61e9 (non-interacting; Ising 5.70e9 / 5.57e9).  Sharing a SIMD
+          // between waves costs more than it gains here (f32: 4 x 51 lanes 1.77e10, 8 x 25 lanes 1.52e10).
+          const double waves_per_simd = bpc / 4.0;
+          cost *= 1.0 + 0.1 * std::log2(cand / 16.0);
+          if (waves_per_simd > 1.0) cost *= 1.0 + 0.25 * (waves_per_simd - 1.0);
+        }
+        if (cost < best.cost) best = Shape{cand, wgs_of(cand), cost};
+      }
+      return best;
+    };
+    Shape pick = shape(false);
+    if (ncases > 1 && supports_packed_cases(h->cfg)) {
+      const Shape pk = shape(true);
+      const char *pe = getenv("PSTAT_PACK");     // 0 | 1: tests and experiments
+      if (pe ? atoi(pe) != 0 : pk.cost < 0.95 * pick.cost) {
+        pick = pk;
+        h->cfg.packed = 1;
+        A.packed = 1;
+      }
     }
-    lanes = best;
+    lanes = pick.lanes;
     A.lanes = lanes;
-    A.blocks_per_case = (h->base.num_chains + lanes - 1) / lanes;
-  }
-  if (cluster_gm) {
-    // Chains in device memory: nothing limits a wave to fewer than 64 lanes, but an ensemble of fewer waves than the
-    // chip has SIMDs (a phase scan: 546 grid points x 64 chains) runs faster as more, emptier waves -- they fill the
-    // idle SIMDs, and a wave's step lasts as long as its LONGEST cluster, which grows like the logarithm of its lanes.
-    hipDeviceProp_t prop;
-    CREATE_HIP(hipGetDeviceProperties(&prop, h->device));
-    int lds0 = 0, bpc = 0;
-    CREATE_HIP(kernel_info(h->cfg, h->args, &lds0, &bpc, nullptr));
-    const double slots = (double)(bpc > 0 ? bpc : 1) * prop.multiProcessorCount;
-    const char *le = getenv("PSTAT_LANES");
-    int best = 64;
-    double best_cost = 1e300;
-    for (int cand = 64; cand >= 16; cand >>= 1) {
-      if (le && atoi(le) >= 1 && atoi(le) <= 64 && cand != atoi(le)) continue;
-      const double wgs = (double)ncases * (double)((h->base.num_chains + cand - 1) / cand);
-      double cost = wgs / slots;
-      if (cost < 1.0) cost = 1.0;
-      cost *= 1.0 + 0.1 * std::log2(cand / 16.0);
-      if (cost < best_cost) { best_cost = cost; best = cand; }
-    }
-    lanes = best;
-    A.lanes = lanes;
-    A.blocks_per_case = (h->base.num_chains + lanes - 1) / lanes;
-    if ((uint64_t)lanes * (uint64_t)h->base.n * PSTAT_CLUSTER_GM_CELL >= 0x80000000ull) {
+    A.blocks_per_case = (per_case + lanes - 1) / lanes;
+    A.nblocks = pick.nblocks;
+    if (cluster_gm && (uint64_t)lanes * (uint64_t)h->base.n * (h->base.precision == PSTAT_F64 ? PSTAT_CLUSTER_GM_CELL : 20u) >= 0x80000000ull) {
       pstat_destroy(h);
       return fail(PSTAT_ERR_UNSUPPORTED, "num-monomers = %lld: a wave's working buffer must stay below 2 GiB",
                   (long long)cases[0].n);
     }
+  }
+  // (checked on the FINAL lane count: the job queue counts blocks and (block, segment) jobs in 32 bits)
+  if (A.nblocks > 0x3fffffffLL) {
+    pstat_destroy(h);
+    return fail(PSTAT_ERR_INVALID_ARG, "too many chains for one handle: %lld chain blocks", (long long)A.nblocks);
   }
   if (stream) {
     h->stream = (hipStream_t)stream;
@@ -412,7 +440,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   if (cluster_gm)            // working copy of the chains, [chain block][lane][n] cells of 40 (f64) / 20 (f32) bytes (pstat_cluster_gm.hip)
     CREATE_TRY(alloc(h, &S.work, cluster_gm_work_bytes(h->cfg, A)));
   else if (h->cfg.state_global)   // working copy of the cells, [chain block][n][64] double2 (run_segment, ST = 2)
-    CREATE_TRY(alloc(h, &S.work, (size_t)(A.blocks_per_case * ncases) * n * 64 * 16));
+    CREATE_TRY(alloc(h, &S.work, (size_t)A.nblocks * n * 64 * 16));
   CREATE_TRY(alloc(h, (void **)&h->d_cases, sizeof(CaseConst) * (size_t)ncases));
   CREATE_TRY(alloc(h, (void **)&h->d_queue, sizeof(int) * sweep_queue_ints(h->args)));
   CREATE_TRY(alloc(h, (void **)&h->d_partial, sizeof(double) * reduce_scratch_doubles()));
@@ -495,7 +523,7 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
     }
     return PSTAT_OK;
   }
-  const int64_t blocks = h->args.blocks_per_case * h->ncases;
+  const int64_t blocks = h->args.nblocks;
   const char *env = getenv("PSTAT_SEGMENTS");
   const char *ms = getenv("PSTAT_MAX_SPINS");
   while (nsteps > 0) {
@@ -833,29 +861,69 @@ int pstat_chain_extras(pstat_handle *h, int64_t chain, double extra_sums[2], dou
   return PSTAT_OK;
 }
 
-// checkpoint image: header, then the eleven state buffers in allocation order
+// checkpoint image: header, the cases' current kT, then the eleven state buffers in allocation order
 struct CkptHeader {
   uint64_t magic;
+  int32_t abi_version, header_bytes;
   int64_t n, C, ncases, steps_recorded, step_in_init;
-  int32_t precision, chain_type, energy_type, reserved;
+  int32_t precision, chain_type, energy_type, rng, move_set, umbrella, do_flips, uniform_bits, lag, reserved;
+  uint64_t seed, chain_id0;     // case 0's
+  uint64_t params_fnv;          // fingerprint of everything else a chain's continuation depends on (params_fingerprint)
 };
 static const int kStateBuffers = 11;
 
+// FNV-1a over the options that are not spelled out in the header: every case's physics scalars except its current kT
+// (which the image carries and restore re-instates), its seed and first chain id, the kT it was created with, and the
+// proposal / adaptation options.  A checkpoint continues exactly the run it was taken from, on a handle created with
+// the same options -- anything else would silently be a different Markov chain wearing this one's averages.
+static uint64_t params_fingerprint(const pstat_handle *h) {
+  uint64_t f = 0xcbf29ce484222325ull;
+  auto mix = [&](const void *p, size_t nbytes) {
+    const unsigned char *q = (const unsigned char *)p;
+    for (size_t i = 0; i < nbytes; ++i) { f ^= q[i]; f *= 0x100000001b3ull; }
+  };
+  for (size_t i = 0; i < h->cases.size(); ++i) {
+    const CaseConst &c = h->cases[i];
+    const double v[12] = {c.E0, c.K1, c.K2, c.mu, c.Fz, c.Fx, c.b, c.kappa, c.psi0, c.cluster_prob, c.cutoff_radius, h->kT0[i]};
+    mix(v, sizeof v);
+    mix(&c.seed, sizeof c.seed);
+    mix(&c.chain_id0, sizeof c.chain_id0);
+  }
+  const double a[5] = {h->base.phi_step, h->base.theta_step, h->base.adj_lb, h->base.adj_ub, h->base.adj_scale};
+  mix(a, sizeof a);
+  mix(&h->base.steps_per_adjust, sizeof h->base.steps_per_adjust);
+  mix(&h->base.num_chains, sizeof h->base.num_chains);
+  return f;
+}
+
+static size_t checkpoint_bytes(const pstat_handle *h) {
+  size_t need = sizeof(CkptHeader) + sizeof(double) * (size_t)h->ncases;
+  for (int i = 0; i < kStateBuffers; ++i) need += h->bufs[i].bytes;
+  return need;
+}
+
 int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes) {
   if (!h || !bytes) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
-  size_t need = sizeof(CkptHeader);
-  for (int i = 0; i < kStateBuffers; ++i) need += h->bufs[i].bytes;
+  const size_t need = checkpoint_bytes(h);
   if (!buf) { *bytes = need; return PSTAT_OK; }
   if (*bytes < need) { *bytes = need; return fail(PSTAT_ERR_TOO_SMALL, "checkpoint needs %zu bytes", need); }
   int rc = set_device(h);
   if (rc) return rc;
   rc = sync_checked(h);
   if (rc) return rc;
-  CkptHeader hd{CKPT_MAGIC, h->base.n, h->S.C, h->ncases, h->steps_recorded, h->step_in_init,
-                h->base.precision, h->base.chain_type, h->base.energy_type, h->cfg.lag};
+  CkptHeader hd{};
+  hd.magic = CKPT_MAGIC; hd.abi_version = PSTAT_ABI_VERSION; hd.header_bytes = (int32_t)sizeof(CkptHeader);
+  hd.n = h->base.n; hd.C = h->S.C; hd.ncases = h->ncases;
+  hd.steps_recorded = h->steps_recorded; hd.step_in_init = h->step_in_init;
+  hd.precision = h->base.precision; hd.chain_type = h->base.chain_type; hd.energy_type = h->base.energy_type;
+  hd.rng = h->base.rng; hd.move_set = h->base.move_set; hd.umbrella = h->base.umbrella ? 1 : 0;
+  hd.do_flips = h->base.do_flips ? 1 : 0; hd.uniform_bits = h->args.wide_eps ? 53 : 23; hd.lag = h->cfg.lag;
+  hd.seed = h->cases[0].seed; hd.chain_id0 = h->cases[0].chain_id0;
+  hd.params_fnv = params_fingerprint(h);
   char *q = (char *)buf;
   std::memcpy(q, &hd, sizeof hd);
   q += sizeof hd;
+  for (int i = 0; i < h->ncases; ++i, q += sizeof(double)) std::memcpy(q, &h->cases[(size_t)i].kT, sizeof(double));
   for (int i = 0; i < kStateBuffers; ++i) {
     HIP_TRY(hipMemcpy(q, h->bufs[i].ptr, h->bufs[i].bytes, hipMemcpyDeviceToHost));
     q += h->bufs[i].bytes;
@@ -866,26 +934,60 @@ int pstat_checkpoint(pstat_handle *h, void *buf, size_t *bytes) {
 
 int pstat_restore(pstat_handle *h, const void *buf, size_t bytes) {
   if (!h || !buf) return fail(PSTAT_ERR_INVALID_ARG, "null argument");
-  size_t need = sizeof(CkptHeader);
-  for (int i = 0; i < kStateBuffers; ++i) need += h->bufs[i].bytes;
-  if (bytes < need) return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint is %zu bytes, handle needs %zu", bytes, need);
+  if (bytes < sizeof(CkptHeader)) return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint is %zu bytes: not even a header", bytes);
   CkptHeader hd;
   std::memcpy(&hd, buf, sizeof hd);
-  if (hd.magic != CKPT_MAGIC || hd.n != h->base.n || hd.C != h->S.C || hd.ncases != h->ncases ||
-      hd.precision != h->base.precision || hd.chain_type != h->base.chain_type ||
-      hd.energy_type != h->base.energy_type)
-    return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint header does not match this handle");
+  if (hd.magic != CKPT_MAGIC)
+    return fail(PSTAT_ERR_BAD_CHECKPOINT, "not a checkpoint of this library version (magic %016llx)", (unsigned long long)hd.magic);
+  if (hd.abi_version != PSTAT_ABI_VERSION || hd.header_bytes != (int32_t)sizeof(CkptHeader))
+    return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint written under ABI version %d, this library is version %d", hd.abi_version,
+                PSTAT_ABI_VERSION);
+#define CKPT_SAME(field, mine, what)                                                                              \
+  if ((long long)(hd.field) != (long long)(mine))                                                                 \
+    return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint does not match this handle: %s is %lld in the checkpoint, " \
+                "%lld here", what, (long long)(hd.field), (long long)(mine))
+  CKPT_SAME(n, h->base.n, "num-monomers");
+  CKPT_SAME(C, h->S.C, "the number of chains");
+  CKPT_SAME(ncases, h->ncases, "the number of cases");
+  CKPT_SAME(precision, h->base.precision, "precision");
+  CKPT_SAME(chain_type, h->base.chain_type, "chain-type");
+  CKPT_SAME(energy_type, h->base.energy_type, "energy-type");
+  CKPT_SAME(rng, h->base.rng, "the generator (0 MWC64X, 1 xoshiro128++: the state words mean different things)");
+  CKPT_SAME(move_set, h->base.move_set, "move_set (0 mcmc_eap_chain.jl, 1 mcmc_clustering_eap_chain.jl)");
+  CKPT_SAME(umbrella, h->base.umbrella ? 1 : 0, "umbrella-sampling");
+  CKPT_SAME(do_flips, h->base.do_flips ? 1 : 0, "do-flips");
+  CKPT_SAME(uniform_bits, h->args.wide_eps ? 53 : 23, "uniform_bits");
+#undef CKPT_SAME
+  if (hd.seed != h->cases[0].seed || hd.chain_id0 != h->cases[0].chain_id0)
+    return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint does not match this handle: seed / chain_id0 %llu / %llu in the "
+                "checkpoint, %llu / %llu here", (unsigned long long)hd.seed, (unsigned long long)hd.chain_id0,
+                (unsigned long long)h->cases[0].seed, (unsigned long long)h->cases[0].chain_id0);
+  if (hd.params_fnv != params_fingerprint(h))
+    return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint does not match this handle: a physics scalar, a case's seed or chain "
+                "ids, num-chains, or a proposal / adaptation option differs from the run it was taken from");
+  const size_t need = checkpoint_bytes(h);
+  if (bytes < need) return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint is truncated: %zu bytes, this handle's image has %zu", bytes, need);
+  const char *q = (const char *)buf + sizeof hd;
+  std::unique_ptr<double[]> kT(new (std::nothrow) double[(size_t)h->ncases]);
+  if (!kT) return fail(PSTAT_ERR_NOMEM, "host allocation failed");
+  for (int i = 0; i < h->ncases; ++i, q += sizeof(double)) {
+    std::memcpy(&kT[(size_t)i], q, sizeof(double));
+    if (!(kT[(size_t)i] > 0) || !std::isfinite(kT[(size_t)i]))
+      return fail(PSTAT_ERR_BAD_CHECKPOINT, "checkpoint holds kT = %g for case %d", kT[(size_t)i], i);
+  }
   int rc = set_device(h);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
-  const char *q = (const char *)buf + sizeof hd;
+  // the temperature of every case as it was when the image was taken (a rung of the burn-in ladder: pstat_scale_kT / pstat_set_kT)
+  for (int i = 0; i < h->ncases; ++i) h->cases[(size_t)i].kT = kT[(size_t)i];
+  HIP_TRY(hipMemcpy(h->d_cases, h->cases.data(), sizeof(CaseConst) * (size_t)h->ncases, hipMemcpyHostToDevice));
   for (int i = 0; i < kStateBuffers; ++i) {
     HIP_TRY(hipMemcpy(h->bufs[i].ptr, q, h->bufs[i].bytes, hipMemcpyHostToDevice));
     q += h->bufs[i].bytes;
   }
   h->steps_recorded = hd.steps_recorded;
   h->step_in_init = hd.step_in_init;
-  h->cfg.lag = hd.reserved;
+  h->cfg.lag = hd.lag;
   return PSTAT_OK;
 }
 
@@ -904,7 +1006,8 @@ int pstat_launch_info_get(pstat_handle *h, pstat_launch_info *out) {
   out->lds_bytes = lds;
   out->threads_per_block = 64;
   out->lanes_per_block = h->args.lanes;
-  out->blocks = all_pairs(h->base.energy_type) ? h->S.C : h->args.blocks_per_case * h->ncases;
+  out->blocks = all_pairs(h->base.energy_type) ? h->S.C : h->args.nblocks;
+  out->packed_cases = h->args.packed;
   out->blocks_per_cu = bpc;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));

@@ -204,7 +204,8 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
 
     for (int s = 0; s < chunk; ++s) {
       // ---- the single-monomer part, mcmc_clustering_eap_chain.jl:269-272
-      const int idx = (int)__umulhi(g.next(), (uint32_t)n);
+      const uint32_t w0 = g.next();
+      const int idx = (int)__umulhi(w0, (uint32_t)n);
       const uint32_t wphi = g.next(), wth = g.next();
       const int cell = idx * lanes + lane;
       const Cell c0 = ang[cell];
@@ -378,7 +379,7 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
         // (the f32 filter of pstat_math.h decides all but ~1e-5 of the draws; the literal expression the rest)
         ok = metropolis_filter(dU * (-1.0 / kT) + (dw - lag), st1 * alpha, st0, weps, [&]() -> bool {
           const R delta = -dU / kT + log_r(st1 / st0) + dw + log_r(alpha) - lag;
-          const R eps = u01<R>(weps);
+          const R eps = (R)eps_uniform(A.wide_eps != 0, weps, w0, wphi, wth);
           return (delta >= 0) || (eps < exp_r(delta));
         });
       } else {

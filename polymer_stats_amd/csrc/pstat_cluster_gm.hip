@@ -251,11 +251,12 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
 
   // ---- the draws whose place in the stream is fixed (mcmc_clustering_eap_chain.jl:269-272 and the skip draw of
   // cluster_flip!, inc/eap_chain.jl:276) and the WINDOW they address
-  struct Draw { int idx; uint32_t wphi, wth; bool flipped; };
+  struct Draw { int idx; uint32_t w0, wphi, wth; bool flipped; };
   struct Win { P2 c0a, c0b, c0c, ua[W + 1], ub[W + 1], da[W + 1], db[W + 1]; };
   auto draw_next = [&]() __attribute__((always_inline)) -> Draw {
     Draw d;
-    d.idx = (int)__umulhi(g.next(), (uint32_t)n);
+    d.w0 = g.next();
+    d.idx = (int)__umulhi(d.w0, (uint32_t)n);
     d.wphi = g.next(); d.wth = g.next();
     d.flipped = !(u01<R>(g.next()) <= cprob);
     return d;
@@ -535,7 +536,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
                                st0 * (lag_pending ? lag_alpha : (R)1), weps, [&]() -> bool {
           const R lg = lag_pending ? log_r(lag_alpha) : lag;
           const R delta = -dU / kT + log_r(st1 / st0) + dw + log_r(alpha) - lg;
-          const R eps = u01<R>(weps);
+          const R eps = (R)eps_uniform(A.wide_eps != 0, weps, d.w0, wphi, wth);
           return (delta >= 0) || (eps < exp_r(delta));
         });
       } else {   // f32: the same test with the logarithm folded away, (1 + u) sin0 < sin1 e alpha + sin0 (cf. pstat_cluster.hip)
@@ -688,35 +689,37 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
 #ifndef PSTAT_GM_WAVES_F32
 #define PSTAT_GM_WAVES_F32 2   // f32 fits 256 registers with ~20 spilled ones: a second wave per SIMD hides latency for ensembles >= 131 072 chains (+10...19 %)
 #endif
-template <typename R, typename G, int CT, int EN>
+template <typename R, typename G, int CT, int EN, bool PACKED>
 __global__ __launch_bounds__(64, sizeof(R) == 4 ? PSTAT_GM_WAVES_F32 : PSTAT_GM_WAVES) void cluster_gm_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
                                                         int umbrella, int *__restrict__ queue) {
   const int lane = threadIdx.x;
-  run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len, int blk) {
+  run_job_queue<PACKED>(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len, int blk) {
     run_cluster_segment_gm<R, G, CT, EN>(A, S, cc, umbrella, lane, chain, first, len, blk);
   }, cases);
 }
 
 using ClusterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int *);
 
-template <typename R, typename G>
+template <typename R, typename G, bool PACKED>
 ClusterFn pick_ct_en(const LaunchCfg &cfg) {
   const bool ising = cfg.energy_type == PSTAT_ISING;
   if (cfg.chain_type == PSTAT_DIELECTRIC)
-    return ising ? cluster_gm_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_ISING> : cluster_gm_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING>;
-  return ising ? cluster_gm_kernel<R, G, PSTAT_POLAR, PSTAT_ISING> : cluster_gm_kernel<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING>;
+    return ising ? cluster_gm_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_ISING, PACKED> : cluster_gm_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING, PACKED>;
+  return ising ? cluster_gm_kernel<R, G, PSTAT_POLAR, PSTAT_ISING, PACKED> : cluster_gm_kernel<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING, PACKED>;
 }
 
-ClusterFn pick(const LaunchCfg &cfg) {
+template <bool PACKED>
+ClusterFn pick_p(const LaunchCfg &cfg) {
   const bool xo = cfg.rng == PSTAT_RNG_XOSHIRO128PP;
-  if (cfg.precision == PSTAT_F64) return xo ? pick_ct_en<double, Xoshiro128pp>(cfg) : pick_ct_en<double, Mwc64x>(cfg);
-  return xo ? pick_ct_en<float, Xoshiro128pp>(cfg) : pick_ct_en<float, Mwc64x>(cfg);
+  if (cfg.precision == PSTAT_F64) return xo ? pick_ct_en<double, Xoshiro128pp, PACKED>(cfg) : pick_ct_en<double, Mwc64x, PACKED>(cfg);
+  return xo ? pick_ct_en<float, Xoshiro128pp, PACKED>(cfg) : pick_ct_en<float, Mwc64x, PACKED>(cfg);
 }
+ClusterFn pick(const LaunchCfg &cfg) { return cfg.packed ? pick_p<true>(cfg) : pick_p<false>(cfg); }
 
 }  // namespace
 
 size_t cluster_gm_work_bytes(const LaunchCfg &cfg, const SweepArgs &a) {
-  return (size_t)(a.blocks_per_case * a.ncases) * (size_t)a.lanes * (size_t)a.n *
+  return (size_t)a.nblocks * (size_t)a.lanes * (size_t)a.n *
          (cfg.precision == PSTAT_F64 ? cell_bytes<double>() : cell_bytes<float>());
 }
 
@@ -728,7 +731,8 @@ hipError_t cluster_gm_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int 
   if (e != hipSuccess) return e;
   if (lds_bytes) *lds_bytes = 0;
   if (blocks_per_cu) *blocks_per_cu = nb;
-  if (name) *name = cfg.precision == PSTAT_F64 ? "cluster_kernel<double, state in memory>" : "cluster_kernel<float, state in memory>";
+  if (name) *name = cfg.precision == PSTAT_F64 ? (cfg.packed ? "cluster_kernel<double, state in memory> [packed cases]" : "cluster_kernel<double, state in memory>")
+                                                : (cfg.packed ? "cluster_kernel<float, state in memory> [packed cases]" : "cluster_kernel<float, state in memory>");
   return hipSuccess;
 }
 

@@ -195,12 +195,14 @@ void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ 
 
     for (int k = 0; k < (int)chunk; ++k) {
       // ---- the single-monomer part of the proposal, mcmc_clustering_eap_chain.jl:269-272
-      const int idx = (int)__umulhi(g.next(), (uint32_t)n);
+      const uint32_t w0 = g.next();
+      const int idx = (int)__umulhi(w0, (uint32_t)n);
       // (the trajectory itself: each product rounded before its sum -- through an opaque register, so that no build flag
       // can fuse them; cf. run_segment)
       auto rounded = [](R v) __attribute__((always_inline)) -> R { asm volatile("" : "+v"(v)); return v; };
-      const R dphi = rounded(phistep * sym11<R>(g.next()));
-      const R dth = rounded(thstep * sym11<R>(g.next()));
+      const uint32_t wphi = g.next(), wth = g.next();
+      const R dphi = rounded(phistep * sym11<R>(wphi));
+      const R dth = rounded(thstep * sym11<R>(wth));
       const R th0 = at(cur.th, idx), ph0 = at(cur.ph, idx);
       const R ph1 = AG::wrap(ph0 + dphi);
       const R th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
@@ -265,7 +267,10 @@ void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ 
           }
         }
       }
-      const R eps = u01<R>(g.next());
+      const uint32_t weps = g.next();
+      R eps;       // f64: 53 random bits by default (eps_uniform, pstat_math.h); f32: the 23 its mantissa holds
+      if constexpr (sizeof(R) == 8) eps = eps_uniform(A.wide_eps != 0, weps, w0, wphi, wth);
+      else eps = u01<R>(weps);
 
       // ---- the trial chain, re-derived (what move!/refl_n! do per touched monomer, :230-257) and its energy
       derive(tr);

@@ -75,6 +75,10 @@ struct SweepArgs {
   int32_t nseg;              // segments per chain block in this launch
   int32_t max_spins;         // bound on the predecessor wait (each spin sleeps ~2 us)
   int32_t lds_rows;          // f64 state-in-memory sweep: monomers [0, lds_rows) keep their cells in LDS
+  int32_t wide_eps;          // f64 kernels: the Metropolis eps carries 53 random bits (pstat_params.uniform_bits; eps_uniform, pstat_math.h)
+  int64_t nblocks;           // chain blocks (workgroup-sized groups of `lanes` chains) of the whole handle
+  int32_t packed;            // 1: a block holds `lanes` CONSECUTIVE GLOBAL chains, i.e. several cases when a case has fewer
+                             // chains than a wave has lanes (run_job_queue<true>); 0: blocks never straddle a case
   int32_t pad_;
 };
 
@@ -92,7 +96,8 @@ struct SweepArgs {
 //  PSTAT_RNG_XOSHIRO128PP: xoshiro128++ seeded per chain by Philox4x32-10(key = seed,
 //      ctr = (chain_lo, chain_hi, 0x5eed, 0)).
 //
-//  u(w) = (w >> 9) * 2^-23;  idx = mulhi32(w, n).
+//  u(w) = (w >> 9) * 2^-23;  idx = mulhi32(w, n).  The f64 kernels' Metropolis eps has 53 bits by default, made of its own
+//  word and the unused low bits of the step's other draws (eps_uniform, pstat_math.h; pstat_params.uniform_bits).
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -202,10 +207,17 @@ struct Mwc64x {
 // waits on still earlier jobs; the wait is bounded (max_spins) and a timeout is reported through the
 // queue's error word.  `body(case constants, global chain, first step, number of steps, chain block)` runs one
 // segment of one lane's chain.
-template <typename Body>
+//
+// Which chains a block holds.  PACKED = false: blocks never straddle a case -- block (case, j) holds chains j * lanes ... of
+// that case, so the case's physics scalars are wave-uniform and live in SGPRs; a case of 16 chains lights 16 lanes.
+// PACKED = true (pstat_create picks it when it shortens the launch: the reference's own sweeps run 1-25 chains per case,
+// run/K1_E0-kT-phase.jl:19-45): block b holds the `lanes` consecutive GLOBAL chains b * lanes ..., whichever cases they
+// belong to; lane -> (case, chain) by one division per job, and `cases[icase]` is then a per-lane load, so the same body
+// compiles with the case's scalars in VGPRs.  A chain's trajectory does not depend on which lanes share its wave.
+template <bool PACKED = false, typename Body>
 __device__ __forceinline__ void run_job_queue(const SweepArgs &A, int *__restrict__ queue, const int lane, Body &&body,
                                               const CaseConst *__restrict__ cases) {
-  const int nblocks = (int)(A.blocks_per_case * A.ncases);
+  const int nblocks = (int)A.nblocks;
   const int njobs = nblocks * A.nseg;
   int *error = queue, *head = queue + 1, *done = queue + 2;   // the error word is sticky: launches clear queue[1..]
   bool failed = false;
@@ -230,14 +242,20 @@ __device__ __forceinline__ void run_job_queue(const SweepArgs &A, int *__restric
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    const int64_t icase = blk / A.blocks_per_case;
-    const int64_t local = (int64_t)(blk % A.blocks_per_case) * A.lanes + lane;
     const int64_t first = (int64_t)seg * A.seg_len;
     const int64_t left = A.nsteps - first;
     const int64_t len = left < A.seg_len ? left : A.seg_len;
     // lanes own disjoint LDS columns and never exchange data: idle lanes just skip the body
-    if (len > 0 && lane < A.lanes && local < A.chains_per_case)
-      body(cases[icase], icase * A.chains_per_case + local, A.step0 + first, len, blk);
+    if constexpr (PACKED) {
+      const int64_t chain = (int64_t)blk * A.lanes + lane;
+      if (len > 0 && lane < A.lanes && chain < A.ncases * A.chains_per_case)
+        body(cases[chain / A.chains_per_case], chain, A.step0 + first, len, blk);
+    } else {
+      const int64_t icase = blk / A.blocks_per_case;
+      const int64_t local = (int64_t)(blk % A.blocks_per_case) * A.lanes + lane;
+      if (len > 0 && lane < A.lanes && local < A.chains_per_case)
+        body(cases[icase], icase * A.chains_per_case + local, A.step0 + first, len, blk);
+    }
     if (A.nseg > 1) {
       // publish: this wave's spill stores are complete and written back before the counter moves
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -256,7 +274,11 @@ struct LaunchCfg {
   int rng;  // PSTAT_RNG_MWC64X | PSTAT_RNG_XOSHIRO128PP
   int move_set;  // PSTAT_MOVES_SINGLE (mcmc_eap_chain.jl) | PSTAT_MOVES_CLUSTER (mcmc_clustering_eap_chain.jl)
   int state_global;  // f64 chain-per-lane kernels: state cells in the global working buffer (DevState::work) instead of LDS
+  int packed;        // chain blocks straddle cases (SweepArgs::packed): the kernel instantiation with per-lane case scalars
 };
+// the chain-per-lane kernel of this configuration has a packed-cases instantiation (sweep: f32 and f64; clustering main:
+// the in-memory kernel, pstat_cluster_gm.hip)
+bool supports_packed_cases(const LaunchCfg &cfg);
 hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                        const CaseConst *cases, double phi_step, double theta_step,
                        const InitOpts &io, hipStream_t stream);

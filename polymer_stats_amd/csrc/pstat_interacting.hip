@@ -224,16 +224,19 @@ __global__ __launch_bounds__(64, M == 8 ? PSTAT_IOCC_M8 :
 
     for (int k = 0; k < (int)chunk; ++k) {
       // ---- proposal (wave-uniform), mcmc_eap_chain.jl:277-280
-      const int idx = (int)__umulhi(g.next(), (uint32_t)n);
+      const uint32_t w0 = g.next();
+      const int idx = (int)__umulhi(w0, (uint32_t)n);
       const int owner = idx / M, slot = idx % M;
       // (the trajectory itself: each product rounded before its sum, as the oracle and Julia round them -- through an
       // opaque register, so that no build flag can fuse them; cf. run_segment)
       auto rounded = [](R v) __attribute__((always_inline)) -> R { asm volatile("" : "+v"(v)); return v; };
-      const R dphi = rounded(phistep * sym11<R>(g.next()));
+      const uint32_t wphi = g.next();
+      const R dphi = rounded(phistep * sym11<R>(wphi));
       const R th0 = at_idx(th, owner, slot), ph0 = at_idx(ph, owner, slot);
       R flip = 0;
       if (do_flips && (g.next() >> 31)) flip = AG::theta_max - rounded(2 * th0);
-      const R dth = flip + rounded(thstep * sym11<R>(g.next()));
+      const uint32_t wth = g.next();
+      const R dth = flip + rounded(thstep * sym11<R>(wth));
       const uint32_t weps = g.next();
       const R eps = u01<R>(weps);
       (void)eps;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(64, M == 8 ? PSTAT_IOCC_M8 :
       bool ok;
       const R dw = du * wscale;   // change of the umbrella weight function (0 if off)
       if constexpr (sizeof(R) == 8) {
-        ok = metropolis_f64(dU, kT, -1.0 / kT, st1, st0, dw - lag, weps);
+        ok = metropolis_f64(dU, kT, -1.0 / kT, st1, st0, dw - lag, A.wide_eps != 0, weps, w0, wphi, wth);
       } else {
         const R e = __builtin_amdgcn_exp2f((R)1.44269504f * (dw - lag) + dU * nbeta_log2e);
         ok = eps * st0 < st1 * e;

@@ -129,12 +129,14 @@ __global__ void init_kernel(SweepArgs A, DevState S, const CaseConst *__restrict
 
 struct Draw {  // raw words of one step's proposal, mcmc_eap_chain.jl:277-280,287
   uint32_t idx, cell, wphi, wth, weps, wflip;   // cell = byte offset of the monomer's LDS slot [idx][lane]
+  uint32_t w0;                                  // the index draw's raw word (its low bits feed the 53-bit eps, pstat_math.h)
 };
 
 template <bool RARE, typename G>
 __device__ __forceinline__ Draw draw_step(G &g, uint32_t n, bool flips, uint32_t row_bytes, uint32_t lane_bytes) {
   Draw d;
-  d.idx = __umulhi(g.next(), n);
+  d.w0 = g.next();
+  d.idx = __umulhi(d.w0, n);
   d.cell = __umul24(d.idx, row_bytes) + lane_bytes;   // one v_mad_u32_u24 (idx < 2^24, a row < 2^24 bytes)
   d.wphi = g.next();
   d.wflip = 0;
@@ -631,7 +633,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       R dw = 0;
       if constexpr (RARE) dw = du * wscale;   // change of the umbrella weight function (0 if off)
       if constexpr (sizeof(R) == 8) {
-        ok = metropolis_f64(dU, kT, ninv_kT, st1, st0, dw - lag, d.weps);
+        ok = metropolis_f64(dU, kT, ninv_kT, st1, st0, dw - lag, A.wide_eps != 0, d.weps, d.w0, d.wphi, d.wth);
       } else {
         // same test with the logarithm folded away: eps * sin(th0) < sin(th1) * exp(-dU/kT + dw - lag)
         R e;
@@ -839,13 +841,14 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
 }
 
 // Persistent sweep kernel: run_segment under the (block, segment) job loop of pstat_device.h.
-template <typename R, typename G, int CT, int EN, bool FX, bool RARE, int ST>
+// PACKED: chain blocks straddle cases, the case's scalars are per-lane values (run_job_queue, pstat_device.h).
+template <typename R, typename G, int CT, int EN, bool FX, bool RARE, int ST, bool PACKED = false>
 __global__ __launch_bounds__(64) void sweep_kernel(SweepArgs A, DevState S,
                                                    const CaseConst *__restrict__ cases,
                                                    SweepRare rare, int *__restrict__ queue) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
-  run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len, int blk) {
+  run_job_queue<PACKED>(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len, int blk) {
     run_segment<R, G, CT, EN, FX, RARE, ST>(A, S, cc, rare, smem, lane, chain, first, len, blk);
   }, cases);
 }
@@ -1022,20 +1025,25 @@ using SweepFn = void (*)(SweepArgs, DevState, const CaseConst *, SweepRare, int 
 #ifdef PSTAT_PART
 // One object per state format: 1 = f32 (turns), 2 = q16 (lattice, f32 arithmetic), 3 = f64 with the cells in LDS,
 // 4 = f64 with the cells in global memory.
-template <typename G, int CT, int EN, bool FX, bool RARE>
+template <typename G, int CT, int EN, bool FX, bool RARE, bool PACKED = false>
 static SweepFn pick_state() {
 #if PSTAT_PART == 4
-  return sweep_kernel<double, G, CT, EN, FX, RARE, 2>;
+  return sweep_kernel<double, G, CT, EN, FX, RARE, 2, PACKED>;
 #elif PSTAT_PART == 3
-  return sweep_kernel<double, G, CT, EN, FX, RARE, 0>;
+  return sweep_kernel<double, G, CT, EN, FX, RARE, 0, PACKED>;
 #elif PSTAT_PART == 2
-  return sweep_kernel<float, G, CT, EN, FX, RARE, 1>;
+  return sweep_kernel<float, G, CT, EN, FX, RARE, 1, PACKED>;
 #else
-  return sweep_kernel<float, G, CT, EN, FX, RARE, 0>;
+  return sweep_kernel<float, G, CT, EN, FX, RARE, 0, PACKED>;
 #endif
 }
 template <typename G, int CT, int EN>
 static SweepFn pick_flags(const LaunchCfg &cfg) {
+#if PSTAT_PART != 2
+  // packed cases: ONE instantiation per (generator, chain, energy) -- the general one (Fx term and the rare options compiled
+  // in, switched by their wave-uniform flags), which makes the same decisions as the specialised ones
+  if (cfg.packed) return pick_state<G, CT, EN, true, true, true>();
+#endif
   const bool rare = cfg.do_flips || cfg.lag || cfg.umbrella;
   if (cfg.has_fx) return rare ? pick_state<G, CT, EN, true, true>() : pick_state<G, CT, EN, true, false>();
   return rare ? pick_state<G, CT, EN, false, true>() : pick_state<G, CT, EN, false, false>();
@@ -1098,6 +1106,12 @@ bool f64_state_global(const LaunchCfg &cfg, int64_t n, int64_t total_chains) {
 
 static int cell_bytes(int precision) { return precision == PSTAT_F64 ? 16 : (precision == PSTAT_Q16 ? 4 : 8); }
 
+bool supports_packed_cases(const LaunchCfg &cfg) {
+  if (cfg.energy_type != PSTAT_NONINTERACTING && cfg.energy_type != PSTAT_ISING) return false;   // all-pairs: a chain per wave
+  if (cfg.move_set == PSTAT_MOVES_CLUSTER) return cfg.state_global != 0;
+  return cfg.precision != PSTAT_Q16;
+}
+
 int choose_lanes(int precision, int64_t n, int energy_type) {
   (void)energy_type;
   const int64_t per_lane = n * cell_bytes(precision);
@@ -1129,13 +1143,15 @@ hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_
   if (e != hipSuccess) return e;
   if (lds_bytes) *lds_bytes = lds;
   if (blocks_per_cu) *blocks_per_cu = nb;
-  if (name) *name = cfg.precision == PSTAT_F64 ? (cfg.state_global ? "sweep_kernel<double, state in L2>" : "sweep_kernel<double>")
-                 : (cfg.precision == PSTAT_Q16 ? "sweep_kernel<float, q16 state>" : "sweep_kernel<float>");
+  if (name) *name = cfg.precision == PSTAT_F64 ? (cfg.state_global ? (cfg.packed ? "sweep_kernel<double, state in L2> [packed cases]" : "sweep_kernel<double, state in L2>")
+                                                                   : (cfg.packed ? "sweep_kernel<double> [packed cases]" : "sweep_kernel<double>"))
+                 : (cfg.precision == PSTAT_Q16 ? "sweep_kernel<float, q16 state>"
+                                               : (cfg.packed ? "sweep_kernel<float> [packed cases]" : "sweep_kernel<float>"));
   return hipSuccess;
 }
 
 // queue layout: [0] error flag (sticky: never cleared by a launch), [1] job counter, [2 ..] per-block "segments done"
-size_t sweep_queue_ints(const SweepArgs &a) { return 2 + (size_t)(a.blocks_per_case * a.ncases); }
+size_t sweep_queue_ints(const SweepArgs &a) { return 2 + (size_t)a.nblocks; }
 
 hipError_t launch_sweep(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                         const CaseConst *cases, int *queue, unsigned grid, hipStream_t stream) {

@@ -96,15 +96,33 @@ __device__ __forceinline__ R sym11(uint32_t w) {  // 2u - 1 in [-1,1)
   else return (R)2 * ((R)(w >> 9) * (R)(1.0 / 8388608.0)) - (R)1;
 }
 
+// The uniform eps of the Metropolis test (mcmc_eap_chain.jl:287: rand(), a Float64 with 53 random bits) under the two
+// stream contracts of pstat_params.uniform_bits (include/pstat.h):
+//   23 bits   eps = (w_eps >> 9) 2^-23 -- the f32 kernels' mantissa trick; acceptance probabilities have a floor of 2^-23
+//   53 bits   eps = (w_eps 2^21 + lo) 2^-53 with lo = the bits of the step's OTHER draws that no proposal uses: the low 9 bits
+//             of the dtheta word, the low 9 of the dphi word (a proposal takes the top 23 of each) and the low 3 of the index
+//             word (idx = mulhi(w, n) does not see them for any n < 2^29).  No extra draw: the stream position of every
+//             word is the same under both contracts, and since only the literal branch below ever forms eps in full, the
+//             hot loop pays one f32 instruction for it (the filter's upper bound).
+__device__ __forceinline__ double eps_uniform(const bool wide, const uint32_t weps, const uint32_t w0, const uint32_t wphi,
+                                              const uint32_t wth) {
+  const uint32_t lo = ((wth & 511u) << 12) | ((wphi & 511u) << 3) | (w0 & 7u);
+  const double e53 = __builtin_fma((double)weps, 2097152.0, (double)lo) * 0x1p-53;   // exact: < 2^53
+  const double e23 = (double)(weps >> 9) * (1.0 / 8388608.0);
+  return wide ? e53 : e23;
+}
+
 // The Metropolis test of the f64 kernels (inc/acceptance.jl:29-39 with the cached log-density written as a
-// difference):  ok = (delta >= 0) || (eps < exp(delta)),  delta = -dU/kT + log(st1/st0) + extra,  eps = u01(weps).
+// difference):  ok = (delta >= 0) || (eps < exp(delta)),  delta = -dU/kT + log(st1/st0) + extra,  eps as above.
 // The literal expression costs a log, an exp and two divisions in double (~95 instructions).  Since eps < 1, the test
 // is  eps * st0 < st1 * exp(-dU/kT + extra)  wherever that product is finite, and an f32 evaluation of the two sides
 // (v_exp_f32, three conversions) decides it whenever they differ by more than the f32 error bound m: only draws
 // within a relative 1e-5 of the threshold -- one wave-step in ~1500 -- run the literal double expression, whose
 // verdict is then taken unchanged.  The decision is therefore ALWAYS the literal one (the bit-parity tests against
-// the oracle hold); the filter only spares its evaluation.  NaN, +-inf, underflow to 0 and eps = 0 all land in the
-// literal branch or on the side the literal test takes.
+// the oracle hold); the filter only spares its evaluation.  The filter sees the top 23 bits u of eps only, i.e. eps in
+// [u, u + 2^-23) under either contract: it accepts on the upper end of that interval and rejects on the lower, so a draw
+// whose low bits could matter (u * den within 2^-23 den of the threshold) goes to the literal branch too.  NaN, +-inf,
+// underflow to 0 and eps = 0 all land in the literal branch or on the side the literal test takes.
 // x = everything in delta except the logarithm of the ratio num / den (sweep: num / den = sin(theta') / sin(theta); clustering
 // main: times the Hastings ratio alpha); literal() = the reference's expression, evaluated only in the rare branch.
 template <typename Literal>
@@ -112,9 +130,11 @@ __device__ __forceinline__ bool metropolis_filter(const double x, const double n
                                                   Literal &&literal) {
   const float t = (float)x;
   const float e = __builtin_amdgcn_exp2f(t * 1.44269504f);
-  const float lhs = (__uint_as_float(0x3F800000u | (weps >> 9)) - 1.0f) * (float)den, rhs = e * (float)num;
+  const float fden = (float)den;
+  const float lhs = (__uint_as_float(0x3F800000u | (weps >> 9)) - 1.0f) * fden, rhs = e * (float)num;
+  const float lhs_hi = __builtin_fmaf(0x1p-23f, fden, lhs);     // (u + 2^-23) den: eps is below it whatever its low bits
   const float m = 2e-6f + 1e-6f * __builtin_fabsf(t);          // > 3x the f32 error of rhs / lhs
-  const bool acc = __builtin_fmaf(lhs, m, lhs) < rhs, rej = lhs > __builtin_fmaf(rhs, m, rhs);
+  const bool acc = __builtin_fmaf(lhs_hi, m, lhs_hi) < rhs, rej = lhs > __builtin_fmaf(rhs, m, rhs);
   bool ok = acc;
   if (__builtin_amdgcn_ballot_w64(!(acc || rej)) != 0) {        // some lane is too close to call (or not finite)
     const bool lit = literal();
@@ -123,10 +143,11 @@ __device__ __forceinline__ bool metropolis_filter(const double x, const double n
   return ok;
 }
 __device__ __forceinline__ bool metropolis_f64(const double dU, const double kT, const double ninv_kT, const double st1,
-                                               const double st0, const double extra, const uint32_t weps) {
+                                               const double st0, const double extra, const bool wide, const uint32_t weps,
+                                               const uint32_t w0, const uint32_t wphi, const uint32_t wth) {
   return metropolis_filter(dU * ninv_kT + extra, st1, st0, weps, [&]() -> bool {
     const double delta = -dU / kT + log_f64(st1 / st0) + extra;
-    const double eps = (double)(weps >> 9) * (1.0 / 8388608.0);
+    const double eps = eps_uniform(wide, weps, w0, wphi, wth);
     return (delta >= 0) || (eps < exp_f64(delta));
   });
 }

@@ -26,7 +26,7 @@ import numpy as np
 
 from . import _lib
 from .julia_fmt import jl_float, jl_row, jl_vector
-from .mcmc_eap_chain import Averager, ReferenceError_, _Pool, _averagers, _log, get_avg, resolve_seed
+from .mcmc_eap_chain import Averager, CsvFiles, ReferenceError_, _Pool, _averagers, _log, get_avg, resolve_seed
 
 ROLL_HEADER = "step,r1,r2,r3,r1sq,r2sq,r3sq,rsq,p1,p2,p3,p1sq,p2sq,p3sq,psq,U,Usq,Ealign,psi"   # :259
 
@@ -187,13 +187,10 @@ def _stage(pool, nsteps, mult, write: bool):
     plist = pool.plist
     pargs = plist[0]
     stepout = int(pargs["stepout"]) if write else 0
-    files = []
+    files = None
     try:
-        for p in plist if write else []:
-            outfile, rollfile = open(f"{p['prefix']}_trajectory.csv", "w"), open(f"{p['prefix']}_rolling.csv", "w")
-            files.append((outfile, rollfile))
-            outfile.write(traj_header(p["num-monomers"]) + "\n")
-            rollfile.write(ROLL_HEADER + "\n")
+        if write:
+            files = CsvFiles([p["prefix"] for p in plist], [traj_header(p["num-monomers"]) for p in plist], ROLL_HEADER)
         start = last_update = time.time()
         step = 0
         while step < nsteps:
@@ -207,23 +204,21 @@ def _stage(pool, nsteps, mult, write: bool):
                 _log(pargs, 3, "Info", f"step:    {step} / {nsteps}")
                 last_update = time.time()
             if stepout > 0 and step % stepout == 0:                     # :312-335
-                for k, (outfile, rollfile) in enumerate(files):
+                for k in range(len(files) if files else 0):
                     micro = pool.microstate(k)
                     st = pool.chain0(k)
                     mus = _dipoles(plist[k], st["phi"], st["theta"])
                     angles = np.stack([st["phi"], st["theta"]], axis=1).reshape(-1)
                     s = pool.summary(k)
-                    outfile.write(jl_row([step, *micro, *angles, *mus.reshape(-1)]) + "\n")
-                    rollfile.write(jl_row([step, *s.avg, *s.extra_avg]) + "\n")
+                    files.rows(k, jl_row([step, *micro, *angles, *mus.reshape(-1)]), jl_row([step, *s.avg, *s.extra_avg]))
         out = [pool.summary(k) for k in range(len(plist))]
         _log(pargs, 3, "Info", f"total time elapsed: {time.time() - start}")
         for k, s in enumerate(out):
             _log(plist[k], 3, "Info", f"acceptance rate: {s.acceptance_ratio}")
         return out
     finally:
-        for outfile, rollfile in files:
-            outfile.close()
-            rollfile.close()
+        if files:
+            files.close()
 
 
 def run(pargs: dict):

@@ -287,6 +287,51 @@ def _averagers(s):
     return sas, vas, s.acceptance_ratio
 
 
+class CsvFiles:
+    """The `<prefix>_trajectory.csv` / `<prefix>_rolling.csv` pair of every case of an ensemble.  The reference holds its two
+    files open for the whole run (mcmc_eap_chain.jl:256-258,372-373); a batched sweep has thousands of cases, so the handles
+    stay open only while two per case fit the process's descriptor limit with room to spare -- beyond that every row is
+    appended by open/write/close (same bytes on disk)."""
+
+    def __init__(self, prefixes, traj_headers, roll_header):
+        try:
+            import resource
+            limit = resource.getrlimit(resource.RLIMIT_NOFILE)[0]
+        except Exception:
+            limit = 256
+        self.paths = [(f"{p}_trajectory.csv", f"{p}_rolling.csv") for p in prefixes]
+        self.keep_open = 2 * len(self.paths) <= max(0, limit - 64) // 2
+        self.handles = []
+        for (tp, rp), th in zip(self.paths, traj_headers):
+            ft, fr = open(tp, "w"), open(rp, "w")
+            ft.write(th + "\n")
+            fr.write(roll_header + "\n")
+            if self.keep_open:
+                self.handles.append((ft, fr))
+            else:
+                ft.close()
+                fr.close()
+
+    def __len__(self):
+        return len(self.paths)
+
+    def rows(self, k, traj_row, roll_row):
+        if self.keep_open:
+            ft, fr = self.handles[k]
+            ft.write(traj_row + "\n")
+            fr.write(roll_row + "\n")
+        else:
+            for path, row in zip(self.paths[k], (traj_row, roll_row)):
+                with open(path, "a") as f:
+                    f.write(row + "\n")
+
+    def close(self):
+        for ft, fr in self.handles:
+            ft.close()
+            fr.close()
+        self.handles = []
+
+
 def mcmc(nsteps: int, pargs: dict):
     """mcmc(nsteps, pargs) of mcmc_eap_chain.jl:171-376 -> (scalar_averagers, vector_averagers, ar)."""
     return mcmc_cases(nsteps, [pargs])[0]
@@ -306,16 +351,13 @@ def mcmc_cases(nsteps: int, plist: list, write_csv: bool = True, info: dict | No
                               "it has no device implementation")
     pool = _Pool(plist)
     stepout = int(pargs["stepout"]) if write_csv else 0
-    files = []
+    files = None
     try:
         if pargs["burn-in"] > 0:
             ladder = [float(x) for x in pargs["burn-schedule"].strip("[] ").replace(",", ";").split(";") if x.strip()]
             pool.burn_in(int(pargs["burn-in"]), ladder or [1.0])
-        for p in plist if write_csv else []:
-            outfile, rollfile = open(f"{p['prefix']}_trajectory.csv", "w"), open(f"{p['prefix']}_rolling.csv", "w")
-            files.append((outfile, rollfile))
-            outfile.write(TRAJ_HEADER + "\n")       # :257
-            rollfile.write(ROLL_HEADER + "\n")      # :259
+        if write_csv:                                # :256-259
+            files = CsvFiles([p["prefix"] for p in plist], [TRAJ_HEADER] * len(plist), ROLL_HEADER)
         start = last_update = time.time()
         for init in range(1, pargs["num-inits"] + 1):           # :266
             step = 0
@@ -331,11 +373,10 @@ def mcmc_cases(nsteps: int, plist: list, write_csv: bool = True, info: dict | No
                     _log(pargs, 3, "Info", f"step:    {step} / {nsteps}")
                     last_update = time.time()
                 if stepout > 0 and step % stepout == 0:          # :329-348
-                    for k, (outfile, rollfile) in enumerate(files):
+                    for k in range(len(files) if files else 0):
                         micro = pool.microstate(k)
                         s = pool.summary(k)
-                        outfile.write(jl_row([step, *micro]) + "\n")
-                        rollfile.write(jl_row([step, *s.avg]) + "\n")
+                        files.rows(k, jl_row([step, *micro]), jl_row([step, *s.avg]))
             if init < pargs["num-inits"]:                        # :352-361
                 pool.reinit(bool(pargs["force-init"]))
         out = [pool.summary(k) for k in range(len(plist))]
@@ -346,9 +387,8 @@ def mcmc_cases(nsteps: int, plist: list, write_csv: bool = True, info: dict | No
         if info is not None:
             info["kernel"] = pool.kernel()
     finally:
-        for outfile, rollfile in files:
-            outfile.close()
-            rollfile.close()
+        if files:
+            files.close()
         pool.close()
     return [_averagers(s) for s in out]
 

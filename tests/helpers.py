@@ -6,7 +6,7 @@ SHARED = PHYS + ("phi_step", "theta_step", "adj_lb", "adj_ub", "adj_scale", "n",
                  "seed", "chain_type", "energy_type", "do_flips", "umbrella", "rng",
                  # clustering main
                  "bend_mod", "bend_angle", "cluster_prob", "use_x0", "x0_phi", "x0_theta", "dx0_phi", "dx0_theta",
-                 "cutoff_radius")
+                 "cutoff_radius", "uniform_bits")
 
 
 def both(num_steps, num_chains=64, precision=1, chain_id0=0, num_inits=1, force_init=0, stepout=0, **kw):

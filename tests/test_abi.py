@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol(ps):
     for n in names:
         assert hasattr(lib, n), f"libpstat.so does not export {n}"
     assert sorted(ps._lib.SYMBOLS) == names, "binding's symbol list is out of date"
-    assert lib.pstat_abi_version() == 5
+    assert lib.pstat_abi_version() == 6
 
 
 def test_struct_layout_matches_header(ps, tmp_path):
@@ -60,7 +60,7 @@ def test_defaults_are_the_references(ps):
     assert p.phi_step == 3 * math.pi / 8 and p.theta_step == 3 * math.pi / 16
     assert (p.adj_lb, p.adj_ub, p.adj_scale, p.steps_per_adjust) == (0.15, 0.55, 1.1, 2500)
     assert p.n == 100 and p.chain_type == ps.DIELECTRIC and p.energy_type == ps.NONINTERACTING
-    assert p.rng == ps.RNG_MWC64X and p.precision == ps.F64 and p.reserved == 0      # Float64 like the reference
+    assert p.rng == ps.RNG_MWC64X and p.precision == ps.F64 and p.uniform_bits == 0      # Float64 like the reference
     # mcmc_clustering_eap_chain.jl:36-43,87-90,146-148
     assert p.move_set == ps.MOVES_SINGLE and (p.bend_mod, p.bend_angle, p.cluster_prob) == (0.0, 0.0, 0.5)
     assert p.use_x0 == 0 and (p.dx0_phi, p.dx0_theta) == (2 * math.pi, 0.1) and p.cutoff_radius == 7.5
@@ -72,7 +72,7 @@ def test_strerror_and_invalid_arguments(ps):
     assert b"device" in lib.pstat_strerror(-2)
     h = C.c_void_p()
     for bad in (dict(n=0), dict(kT=-1.0), dict(chain_type=7), dict(energy_type=9), dict(num_chains=0),
-                dict(precision=5), dict(phi_step=0.0), dict(rng=3), dict(reserved=1), dict(move_set=2),
+                dict(precision=5), dict(phi_step=0.0), dict(rng=3), dict(uniform_bits=1), dict(uniform_bits=53, precision=0), dict(move_set=2),
                 dict(move_set=1, cluster_prob=1.5), dict(move_set=1, do_flips=1), dict(bend_mod=1.0),
                 dict(use_x0=1, x0_theta=float("nan")), dict(energy_type=3),
                 dict(energy_type=3, move_set=1, cutoff_radius=0.0)):

@@ -1,0 +1,146 @@
+"""Packed cases: when a case has fewer chains than a wave has lanes, pstat_create lets a workgroup hold `lanes` consecutive
+GLOBAL chains, whichever cases they belong to (run_job_queue<true>, csrc/pstat_device.h) -- what the reference's own sweep
+drivers need: one chain per case, 5-25 repeats (run/K1_E0-kT-phase.jl:19-45, run/interacting_dielectric_study.jl:37-47).
+The case's physics scalars then travel per lane (VGPRs) instead of per wave (SGPRs); nothing else may change: a chain's
+trajectory depends on its (seed, chain id) and its case's options, never on which lanes share its wave."""
+import numpy as np
+import pytest
+
+from helpers import both
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ps():
+    import polymer_stats_amd as ps
+    assert ps._lib.load().pstat_device_count() >= 1, "no HIP device visible"
+    return ps
+
+
+def _state_equal(a, b, what):
+    for k in ("theta", "phi", "rng"):
+        assert np.array_equal(a[k], b[k]), (what, k)
+    assert a["nacc_total"] == b["nacc_total"] and a["phi_step"] == b["phi_step"] and a["theta_step"] == b["theta_step"], what
+
+
+# (family, parameters that select the kernel, steps).  n = 30 keeps the f64 sweep's cells in LDS, n = 60 in memory.
+FAMILIES = [
+    ("f64 sweep, cells in LDS", dict(n=30, precision=1), 2500),
+    ("f64 sweep, cells in memory", dict(n=60, precision=1), 2500),
+    ("f64 Ising sweep, cells in memory", dict(n=60, precision=1, energy_type=2, K1=0.3), 2000),
+    ("f64 sweep, rare options", dict(n=60, precision=1, do_flips=1, umbrella=1, Fx=0.3), 2000),
+    ("f64 clustering main", dict(n=40, precision=1, move_set=1, cluster_prob=0.5, bend_mod=0.3, bend_angle=0.2, K2=0.2), 1500),
+    ("f64 clustering main, Ising", dict(n=40, precision=1, move_set=1, cluster_prob=0.4, energy_type=2, K1=0.2), 1500),
+    ("f64 clustering main, polar", dict(n=24, precision=1, move_set=1, cluster_prob=0.5, chain_type=1, mu=0.7), 1500),
+]
+
+
+def _cases(ps, fam_kw, ncases, nchains):
+    out = []
+    for i in range(ncases):
+        kw = dict(E0=0.5 + 0.25 * i, K1=1.0, K2=0.0, kT=0.6 + 0.2 * i, Fz=0.1 * i, b=1.0 + 0.05 * i, seed=300 + i,
+                  chain_id0=1000 * i, num_chains=nchains)
+        kw.update(fam_kw)
+        if fam_kw.get("move_set"):
+            kw["cluster_prob"] = min(0.9, fam_kw["cluster_prob"] + 0.05 * i)      # per-case options of the clustering main
+            kw["bend_mod"] = fam_kw.get("bend_mod", 0.0) * (1 + 0.1 * i)
+        out.append(kw)
+    return out
+
+
+@pytest.mark.parametrize("name,fam_kw,nsteps", FAMILIES, ids=[f[0] for f in FAMILIES])
+def test_packed_batch_equals_single_case_handles_and_the_oracle(ps, oracle, monkeypatch, name, fam_kw, nsteps):
+    """8 cases x 16 chains in one handle, packed four cases to a wave: every chain bit-identical to the same chain in a
+    single-case handle (blocks inside the case, scalars in SGPRs) and to the oracle; per-case averages equal."""
+    cases = _cases(ps, fam_kw, 8, 16)
+    monkeypatch.setenv("PSTAT_PACK", "1")
+    batch = ps.Ensemble([ps.default_params(**kw) for kw in cases])
+    info = batch.launch_info()
+    assert info.packed_cases == 1 and "[packed cases]" in info.kernel.decode(), info.kernel.decode()
+    assert info.blocks == -(-8 * 16 // info.lanes_per_block)
+    batch.advance(nsteps)
+    batch.sync()
+    monkeypatch.setenv("PSTAT_PACK", "0")
+    mode = "cluster" if fam_kw.get("move_set") else "fast"
+    for i, kw in enumerate(cases):
+        with ps.Ensemble(ps.default_params(**kw)) as single:
+            assert single.launch_info().packed_cases == 0
+            single.advance(nsteps)
+            for k in (0, 5, 15):
+                _state_equal(batch.chain_state(i * 16 + k), single.chain_state(k), (name, i, k))
+                np.testing.assert_allclose(batch.chain_state(i * 16 + k)["sums"], single.chain_state(k)["sums"], rtol=1e-12, atol=1e-9)
+            a, _ = batch.rolling(i)
+            b, _ = single.rolling(-1)
+            np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-10)
+        okw = {k: v for k, v in kw.items() if k not in ("num_chains", "precision", "move_set", "chain_id0")}
+        op, _ = both(nsteps, **okw)
+        for k in (0, 15):
+            o = oracle.run(op, chain_id=kw["chain_id0"] + k, mode=mode, trace=True)
+            g = batch.chain_state(i * 16 + k)
+            assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (name, i, k)
+            assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total, (name, i, k)
+    batch.close()
+
+
+@pytest.mark.parametrize("nchains,ncases", [(1, 200), (5, 77), (25, 13), (100, 7)])
+def test_packed_ragged_shapes_and_block_boundaries(ps, monkeypatch, nchains, ncases):
+    """Chains per case that do not divide the wave (1, 5, 25 -- the reference's repeat counts -- and 100): cases straddle
+    waves, the last wave is partly empty.  Packed and unpacked handles agree chain by chain; so does a handle advanced in
+    several launches with time segments (every job refills its block from the checkpoint layout)."""
+    cases = [ps.default_params(n=48, E0=0.3 * (i % 7), K1=1.0, kT=0.5 + 0.1 * (i % 5), Fz=0.05 * (i % 11), seed=900 + i,
+                               num_chains=nchains, precision=ps.F64) for i in range(ncases)]
+    states = {}
+    for pack, segs in (("0", "1"), ("1", "1"), ("1", "3")):
+        monkeypatch.setenv("PSTAT_PACK", pack)
+        monkeypatch.setenv("PSTAT_SEGMENTS", segs)
+        with ps.Ensemble(cases) as e:
+            assert e.launch_info().packed_cases == int(pack)
+            e.advance(700)
+            e.advance(500)
+            total = nchains * ncases
+            states[pack + segs] = [e.chain_state(c) for c in sorted({0, 1, 63, 64, 65, total // 2, total - 1} & set(range(total)))]
+            states[pack + segs + "avg"] = np.array([e.rolling(i)[0] for i in (0, ncases // 2, ncases - 1)])
+    for key in ("11", "13"):
+        for a, b in zip(states["01"], states[key]):
+            _state_equal(a, b, (nchains, ncases, key))
+        np.testing.assert_allclose(states["01avg"], states[key + "avg"], rtol=1e-11, atol=1e-10)
+
+
+def test_pstat_create_packs_when_it_shortens_the_launch_and_only_then(ps, monkeypatch):
+    """The chooser itself (no PSTAT_PACK): an ensemble of many few-chain cases that overflows the chip's resident waves
+    is packed; full-wave cases, a single case, and ensembles that fit the chip either way keep their SGPR scalars."""
+    monkeypatch.delenv("PSTAT_PACK", raising=False)
+    P = lambda **kw: ps.default_params(n=100, E0=1.0, K1=0.0, K2=1.0, precision=ps.F64, **kw)
+    grid = lambda m, nc, **kw: [P(kT=0.5 + 0.001 * i, num_chains=nc, seed=i, **kw) for i in range(m)]
+    cl = dict(move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, energy_type=ps.ISING)
+    with ps.Ensemble(grid(2730, 16, **cl)) as e:         # run/K1_E0-kT-phase.jl: 546 points x 5 runs, 16 chains each here
+        info = e.launch_info()
+        assert info.packed_cases == 1 and info.lanes_per_block == 64 and info.blocks == -(-2730 * 16 // 64)
+    with ps.Ensemble(grid(546, 64, **cl)) as e:          # the phase scan: 64 chains per point divide the wave
+        assert e.launch_info().packed_cases == 0
+    with ps.Ensemble(grid(3000, 16)) as e:               # fixed-force main, f64 cells in memory: 3 000 quarter waves > 1 024 slots
+        info = e.launch_info()
+        assert info.packed_cases == 1 and info.blocks == 750 and "state in L2" in info.kernel.decode()
+    with ps.Ensemble(grid(174, 16)) as e:                # fits the chip either way: nothing to gain
+        assert e.launch_info().packed_cases == 0
+    with ps.Ensemble(P(num_chains=1000, seed=1)) as e:   # one case
+        assert e.launch_info().packed_cases == 0
+    with ps.Ensemble(grid(3000, 16, energy_type=ps.INTERACTING)[:40]) as e:    # all-pairs: a chain per wavefront, nothing to pack
+        assert e.launch_info().packed_cases == 0
+
+
+def test_packed_f32_sweep_statistics_and_unpacked_agreement(ps, monkeypatch):
+    """The f32 fast path packs too (its LDS-sized workgroups hold 51 lanes at n = 100): same chains, same trajectories
+    as unpacked (f32 arithmetic is deterministic per chain)."""
+    cases = [ps.default_params(n=100, E0=1.0, K1=1.0, Fz=0.1 * i, seed=50 + i, num_chains=10, precision=ps.F32) for i in range(40)]
+    out = {}
+    for pack in ("0", "1"):
+        monkeypatch.setenv("PSTAT_PACK", pack)
+        with ps.Ensemble(cases) as e:
+            assert e.launch_info().packed_cases == int(pack)
+            e.advance(3000)
+            out[pack] = ([e.chain_state(c) for c in (0, 9, 10, 199, 399)], np.array([e.rolling(i)[0] for i in range(40)]))
+    for a, b in zip(out["0"][0], out["1"][0]):
+        assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["phi"], b["phi"]) and a["nacc_total"] == b["nacc_total"]
+    np.testing.assert_allclose(out["0"][1], out["1"][1], rtol=1e-5, atol=1e-4)

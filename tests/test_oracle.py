@@ -251,3 +251,36 @@ def test_cluster_oracle_bookkeeping(oracle):
     mu_z = 1.0 * np.cos(th) ** 2                      # K1 = 1, K2 = 0, E0 = 1
     U = -0.5 * mu_z.sum() + 0.35 * ((psi - 0.2) ** 2).sum() - 0.4 * np.cos(th).sum()
     assert o.U == pytest.approx(U, rel=1e-12)
+
+
+def test_metropolis_eps_contracts(oracle):
+    """eap_eps: 23 bits = (w >> 9) 2^-23; 53 bits (the default, uniform_bits = 0 | 53) = the eps word followed by the low 9
+    bits of the dtheta word, the low 9 of the dphi word and the low 3 of the index word -- exact in a double, in [u23, u23 +
+    2^-23), and 0 only if all 53 bits are.  faithful == fast under both, and the two contracts walk one stream."""
+    L = oracle.lib()
+    w_eps, w_idx, w_phi, w_th = 0x89ABCDEF, 0xFFFFFFFD, 0x123451FF, 0x765430AA
+    assert L.eap_eps(23, w_eps, w_idx, w_phi, w_th) == (w_eps >> 9) / 2.0 ** 23
+    want = ((w_eps << 21) | ((w_th & 511) << 12) | ((w_phi & 511) << 3) | (w_idx & 7)) / 2.0 ** 53
+    assert L.eap_eps(53, w_eps, w_idx, w_phi, w_th) == want == L.eap_eps(0, w_eps, w_idx, w_phi, w_th)
+    assert (w_eps >> 9) / 2.0 ** 23 <= want < ((w_eps >> 9) + 1) / 2.0 ** 23
+    assert L.eap_eps(53, 0, 0, 0, 0) == 0.0 and L.eap_eps(53, 0, 1, 0, 0) == 2.0 ** -53
+    assert L.eap_eps(53, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -53
+    kw = dict(n=16, E0=1.2, K1=0.8, K2=0.1, Fz=0.5, Fx=0.2, num_steps=4000, seed=19, do_flips=1, stepout=0)
+    runs = {}
+    for bits in (23, 53):
+        for mode in ("faithful", "fast"):
+            runs[bits, mode] = oracle.run(oracle.make_params(uniform_bits=bits, **kw), chain_id=2, mode=mode, trace=True)
+        a, b = runs[bits, "faithful"], runs[bits, "fast"]
+        assert np.array_equal(a.accepted, b.accepted) and np.array_equal(a.final_theta, b.final_theta) and np.array_equal(a.rng, b.rng)
+    assert np.array_equal(runs[23, "fast"].rng, runs[53, "fast"].rng)       # no extra draw under 53 bits
+    with pytest.raises(RuntimeError):
+        oracle.run(oracle.make_params(uniform_bits=24, **kw), chain_id=0, mode="fast")
+
+
+def test_eps_word_scan_finds_the_23_bit_zeros(oracle):
+    """eap_find_eps23_zero against the stream itself: word 2n + 4s + 3 of the chain's stream is step s's Metropolis word."""
+    P = oracle.make_params(n=7, seed=123, num_steps=1, stepout=0)
+    hits = oracle.find_eps23_zero(P, chain_id=3, nsteps=3_000_000)
+    assert 0 <= len(hits) <= 4
+    _, words = oracle.mwc64x_stream(123, 3, 2 * 7 + 4 * 2000)
+    assert [s for s in range(2000) if words[14 + 4 * s + 3] >> 9 == 0] == [h for h in hits if h < 2000]

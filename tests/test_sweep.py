@@ -101,6 +101,37 @@ def test_aggregator_reads_names_and_lines_like_the_reference(tmp_path):
     assert rows[1].endswith(",9.0,NaN") and len(rows[1].split(",")) == 27
     assert ag.main([str(out)]) == 1 and ag.main([str(out), str(d), "*.out", "rubber"]) == 1
     assert ag.main([str(out), str(d), "*.out", "dielectric", "2D"]) == 1
+    # a file name with fewer tokens than the header has input columns would put every value under the wrong heading (the
+    # reference does so silently, scripts/aggregate_mcmc.jl:54,67-74): refused, nothing misaligned is written
+    d3 = tmp_path / "w3"
+    d3.mkdir()
+    (d3 / "E0-0001000_Fz-0000500_n-0100000.out").write_text(
+        "\n".join(fm.summary_lines(sas[:4], vas, 0.5, dict(mlen=1.0, **{"num-monomers": 100}))) + "\n")
+    assert ag.main([str(tmp_path / "bad.csv"), str(d3), "*.out", "dielectric"]) == 1
+    assert ag.main([str(tmp_path / "bad.csv"), str(d), "*.out", "dielectric", "3D", "true"]) == 1   # run token left in: 10 != 9
+
+
+def test_csv_files_fall_back_to_appending_when_descriptors_run_out(tmp_path):
+    """run_sweep batches up to thousands of cases into one ensemble; --csv then needs two files per case.  Handles stay open
+    only while they fit RLIMIT_NOFILE with room to spare, otherwise every row is appended -- same bytes either way."""
+    import resource
+    from polymer_stats_amd.mcmc_eap_chain import CsvFiles
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    texts = {}
+    try:
+        for tag, lim in (("open", soft), ("append", 80)):
+            resource.setrlimit(resource.RLIMIT_NOFILE, (lim, hard))
+            f = CsvFiles([str(tmp_path / f"{tag}{k}") for k in range(40)], [f"step,h{k}" for k in range(40)], "step,r")
+            assert f.keep_open == (tag == "open") and len(f) == 40
+            for step in (500, 1000):
+                for k in range(40):
+                    f.rows(k, f"{step}.0,{k}.0", f"{step}.0,{k}.5")
+            f.close()
+            texts[tag] = [(tmp_path / f"{tag}{k}_trajectory.csv").read_text() + (tmp_path / f"{tag}{k}_rolling.csv").read_text()
+                          for k in range(40)]
+    finally:
+        resource.setrlimit(resource.RLIMIT_NOFILE, (soft, hard))
+    assert texts["open"] == texts["append"] and texts["open"][7] == "step,h7\n500.0,7.0\n1000.0,7.0\nstep,r\n500.0,7.5\n1000.0,7.5\n"
 
 
 def test_run_sweep_cli_needs_cases_and_a_gpu(tmp_path):
@@ -114,6 +145,10 @@ def test_run_sweep_cli_needs_cases_and_a_gpu(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "36 cases (0 already there), 2 ensemble(s)" in r.stdout and "n = 200, interacting, dielectric, 500000 steps: 18 cases, 72 chains" in r.stdout
     assert "E0-0000100_K1-0000000_K2-0001000_n-0100000_b-0000500.out" in r.stdout and not (tmp_path / "d").exists()
+    # under an external launcher every rank would draw its own fresh base seed: refused before anything runs
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_sweep.py"), str(tmp_path / "x"), "--axis", "n=10", "--gpus", "2"],
+                       capture_output=True, text=True, env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "needs --seed" in r.stderr
     import polymer_stats_amd as ps
     if ps._lib.load().pstat_device_count() < 1:           # the product has no CPU path: say so, write nothing
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_sweep.py"), str(tmp_path / "w"), "--axis", "n=10"],

@@ -90,10 +90,16 @@ def main():
         from rank_spawn import spawn_ranks
         extra = [] if args.seed is not None else ["--seed", str(sw.fixed_main.fresh_seed() & 0x7FFFFFFFFFFF)]
         pre = sys.argv[1:sys.argv.index("--")] if "--" in sys.argv else sys.argv[1:]
-        agg = []
-        if args.aggregate:                      # the ranks only run; the parent aggregates when all of them are done
-            i = pre.index("--aggregate")
-            agg, pre = pre[i:i + 2], pre[:i] + pre[i + 2:]
+        agg = bool(args.aggregate)              # the ranks only run; the parent aggregates when all of them are done
+        kept, skip = [], False
+        for a in pre:                           # drop `--aggregate X` and `--aggregate=X` from what the ranks are given
+            if skip:
+                skip = False
+            elif a == "--aggregate":
+                skip = True
+            elif not a.startswith("--aggregate="):
+                kept.append(a)
+        pre = kept
         rc, out0 = spawn_ranks(os.path.abspath(__file__), pre + extra + (["--"] + fixed if fixed else []), args.gpus)
         sys.stdout.write(out0)
         if rc == 0 and agg:
@@ -104,6 +110,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 and args.seed is None:
+        # started by an external launcher: every rank would draw its own fresh base seed, and case k's seed = base + k must
+        # be the same whichever rank runs it
+        raise SystemExit("run_sweep.py under an external launcher (WORLD_SIZE preset) needs --seed: all ranks must name the same one")
     lib = sw._lib.load()
     ndev = lib.pstat_device_count()
     if ndev < 1:
