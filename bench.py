@@ -116,6 +116,101 @@ def cpu_baseline(n, mc_steps, target_seconds=12.0):
                       f"full recompute per step, fp64, one thread per chain), {wall:.1f} s wall"}, mean, se
 
 
+def cpu_sample(ob, okw, mode, cores, budget_s):
+    """A bounded CPU sample of one configuration in one oracle mode: one single-threaded chain per host thread (the reference's
+    pmap farm), the number of steps sized from a calibration run so that the sample takes about `budget_s` seconds."""
+    cal = 400 if okw.get("energy_type") == 1 else 20000
+    P = ob.make_params(num_steps=cal, seed=11, stepout=0, **okw)
+    t0 = time.perf_counter()
+    ob.run(P, chain_id=0, mode=mode)
+    per_step = max(time.perf_counter() - t0, 1e-5) / cal
+    steps = int(max(cal, min(100_000_000, budget_s / per_step)))
+    P = ob.make_params(num_steps=steps, seed=11, stepout=0, **okw)
+    t0 = time.perf_counter()
+    ob.run_many(P, id0=1, nchains=cores, nthreads=cores, mode=mode)
+    wall = time.perf_counter() - t0
+    return {"value": cores * steps / wall, "sample": f"{cores} chains x {steps} steps in {wall:.2f} s"}
+
+
+def measure_configs(ps, torch, stream, pmc, headline, head_cpu, skip_cpu, budget_s):
+    """One measured line per BASELINE configuration (tools/configs.py), each in f64 -- the reference's arithmetic -- with its
+    roofline fraction (SURVEY 8(d)'s algorithmic work per update), the VALU figures of the stamped PMC record of ITS kernel
+    (profiles/pmc_traffic.json; null when the kernel sources have changed since), and both CPU baselines beside it: the
+    oracle's faithful mode (the reference's literal algorithm: deep copy + full recompute per step) and its fast mode
+    (O(1) energy differences; the best-effort CPU of BASELINE.md section 2).  Not part of the headline's timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from configs import config_list, F64_VECTOR_PEAK_TFLOPS
+    out = []
+    cores = host_cores()
+    ob = None
+    if not skip_cpu:
+        from oracle import binding as ob
+    for cfg in config_list(ps):
+        t_cfg = time.perf_counter()
+        entry = {"id": cfg["id"], "workload": cfg["workload"], "dtype": "f64"}
+        if cfg.get("headline"):
+            rate, kernel_ms, kernel = headline["rate"], headline["kernel_ms"], headline["kernel"]
+            entry["check"] = headline["check"]
+        else:
+            with torch.cuda.stream(stream):
+                with ps.Ensemble(cfg["cases"], stream=stream.cuda_stream) as e:
+                    e.advance(min(cfg["mc_steps"], 4000))          # warm-up: first touch, clocks, the adaptation's regime
+                    torch.cuda.synchronize()
+                    ms = []
+                    for _ in range(2):
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record(stream)
+                        e.advance(cfg["mc_steps"])
+                        b.record(stream)
+                        torch.cuda.synchronize()
+                        ms.append(a.elapsed_time(b))
+                    e.sync()
+                    info, s = e.launch_info(), e.summary()
+                    chains = e.num_chains * e.ncases
+            kernel_ms, kernel = sum(ms) / len(ms), info.kernel.decode()
+            rate = chains * cfg["mc_steps"] / (kernel_ms * 1e-3)
+            entry.update({"chains": chains, "n": int(cfg["cases"][0].n), "mc_steps": cfg["mc_steps"],
+                          "check": {"r3": s.avg[2], "p3": s.avg[9], "U": s.avg[14], "AR": s.acceptance_ratio,
+                                    "nan_rejects": int(s.nan_rejects), "chains_collapsed": int(s.chains_collapsed)}})
+        entry.update({"kernel": kernel, "value": rate, "unit": "MC monomer-updates/s", "kernel_ms": kernel_ms})
+        if "flop_per_update" in cfg:
+            ach = cfg["flop_per_update"] * rate / 1e12
+            entry["roofline"] = {"bound": "valu-f64", "achieved": ach, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": ach / F64_VECTOR_PEAK_TFLOPS,
+                                 "algorithmic": "%d flop per update = n(n-1)/2 pair terms x 36 flop (SURVEY 8(d); the reference's full "
+                                                "recomputation, inc/eap_chain.jl:196-211) against the f64 vector peak" % cfg["flop_per_update"]}
+        else:
+            ach = cfg["bytes_per_update"] * rate / 1e9
+            entry["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                 "algorithmic": "%d B per update: one f64 (theta, phi) cell read and written (SURVEY 8(d))" % cfg["bytes_per_update"]}
+        rec = (pmc or {}).get("records", {}).get(cfg["pmc_record"])
+        if rec:
+            v, f = rec["valu_instructions_per_update_per_lane"], rec.get("valu_f64_instructions_per_update_per_lane") or 0.0
+            entry["valu"] = {"frac": rate * (f / (0.5 * VALU_LANE_OPS_PEAK) + max(0.0, v - f) / VALU_LANE_OPS_PEAK),
+                             "ops_per_update": v, "f64_ops_per_update": f,
+                             "wave_cycles_with_an_instruction": rec.get("wave_cycles_with_an_instruction"),
+                             "wave_cycles_waiting": rec.get("wave_cycles_waiting"),
+                             "traffic_bytes_per_update": (rec["hbm_bytes_per_launch"] / rec["updates_per_launch"])
+                             if rec.get("hbm_bytes_per_launch") and rec.get("updates_per_launch") else None,
+                             "source": "profiles/pmc_traffic.json record '%s' (round %s, stamp = sha256 of the kernel sources)"
+                                       % (cfg["pmc_record"], rec.get("round"))}
+        else:
+            entry["valu"] = None
+        if ob is not None:
+            cb = {"cores": cores, "kind": "port", "unit": "MC monomer-updates/s"}
+            if cfg.get("headline") and head_cpu is not None:
+                cb["faithful"] = {"value": head_cpu["value"], "sample": head_cpu["sample"]}
+            else:
+                cb["faithful"] = cpu_sample(ob, cfg["oracle"], "faithful", cores, budget_s)
+            cb["fast"] = cpu_sample(ob, cfg["oracle"], "fast", cores, budget_s)
+            cb["gpu_over_faithful"] = rate / cb["faithful"]["value"]
+            cb["gpu_over_fast"] = rate / cb["fast"]["value"]
+            entry["cpu_baseline"] = cb
+        log(f"config {cfg['id']}: {rate:.3e} updates/s ({kernel}); {time.perf_counter() - t_cfg:.1f} s")
+        out.append(entry)
+    return out
+
+
 def parity_vs_cpu(ps, prec, n, chains, mc_steps, device, cpu_mean, cpu_se):
     """The north star's acceptance line: <r_z>, <p_z>, <U> of the device path against the CPU restatement run
     under the same options and protocol (same Fz = 1 point, same number of steps, no burn-in on either
@@ -164,6 +259,9 @@ def main():
                     help="per-chain generator (default MWC64X; xoshiro128++ is the north star's named one, measured slower here)")
     ap.add_argument("--no-rng-named", action="store_true", help="skip the sibling f64 measurement under xoshiro128++")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` array (one measured line per BASELINE configuration)")
+    ap.add_argument("--config-cpu-seconds", type=float, default=2.5, help="CPU seconds per configuration and oracle mode")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU seconds of the headline's cpu_baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend; gloo (via host memory) only to rehearse N>1 on a box with fewer GPUs")
@@ -401,12 +499,18 @@ def main():
                                 "roofline_frac": g["roofline"]["frac"], "kernel_ms": g["roofline"]["kernel_ms"], "check": g["check"],
                                 "note": "same kernel, workload, K and W as the headline, which runs the default MWC64X "
                                         "(one v_mad_u64_u32 + one v_xor per draw against ten 32-bit ops; DESIGN.md section 4)"}
+        base = None
         if world == 1 and not args.no_cpu_baseline:
-            base, cpu_mean, cpu_se = cpu_baseline(args.n, args.mc_steps)
+            base, cpu_mean, cpu_se = cpu_baseline(args.n, args.mc_steps, args.cpu_seconds)
             base["parity"] = parity_vs_cpu(ps, PREC[args.precision], args.n, args.chains, args.mc_steps, local_rank, cpu_mean, cpu_se)
             if fast is not None:
                 base["parity_fast_path"] = parity_vs_cpu(ps, ps.F32, args.n, args.chains, args.mc_steps, local_rank, cpu_mean, cpu_se)
             out["cpu_baseline"] = base
+        if world == 1 and not args.no_configs and args.precision == "f64" and args.n == 100:
+            kern_ms = h["roofline"]["kernel_ms"]
+            headline = {"rate": args.chains * args.mc_steps / (kern_ms * 1e-3), "kernel_ms": kern_ms, "kernel": h["kernel"],
+                        "check": h["check"]}
+            out["configs"] = measure_configs(ps, torch, stream, pmc, headline, base, args.no_cpu_baseline, args.config_cpu_seconds)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

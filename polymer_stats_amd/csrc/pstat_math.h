@@ -109,7 +109,11 @@ __device__ __forceinline__ double eps_uniform(const bool wide, const uint32_t we
   const uint32_t lo = ((wth & 511u) << 12) | ((wphi & 511u) << 3) | (w0 & 7u);
   const double e53 = __builtin_fma((double)weps, 2097152.0, (double)lo) * 0x1p-53;   // exact: < 2^53
   const double e23 = (double)(weps >> 9) * (1.0 / 8388608.0);
+#ifdef PSTAT_NARROW_EPS   // (timing experiment, tools/build_variant.sh: what the 53-bit contract costs the hot loop)
+  return e23;
+#else
   return wide ? e53 : e23;
+#endif
 }
 
 // The Metropolis test of the f64 kernels (inc/acceptance.jl:29-39 with the cached log-density written as a
@@ -134,7 +138,12 @@ __device__ __forceinline__ bool metropolis_filter(const double x, const double n
   const float lhs = (__uint_as_float(0x3F800000u | (weps >> 9)) - 1.0f) * fden, rhs = e * (float)num;
   const float lhs_hi = __builtin_fmaf(0x1p-23f, fden, lhs);     // (u + 2^-23) den: eps is below it whatever its low bits
   const float m = 2e-6f + 1e-6f * __builtin_fabsf(t);          // > 3x the f32 error of rhs / lhs
+#ifdef PSTAT_NARROW_EPS
+  const bool acc = __builtin_fmaf(lhs, m, lhs) < rhs, rej = lhs > __builtin_fmaf(rhs, m, rhs);
+  (void)lhs_hi;
+#else
   const bool acc = __builtin_fmaf(lhs_hi, m, lhs_hi) < rhs, rej = lhs > __builtin_fmaf(rhs, m, rhs);
+#endif
   bool ok = acc;
   if (__builtin_amdgcn_ballot_w64(!(acc || rej)) != 0) {        // some lane is too close to call (or not finite)
     const bool lit = literal();

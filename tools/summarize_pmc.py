@@ -135,6 +135,7 @@ def main():
             if "SQ_ACTIVE_INST_ANY" in mean and mean.get("SQ_WAVE_CYCLES") else None,
             "wave_cycles_waiting": (mean["SQ_WAIT_ANY"] / mean["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in mean and mean.get("SQ_WAVE_CYCLES") else None,
             "kernel_ms_rocprof_trace": kern_ms,
+            "updates_per_launch": a.updates,
         }
         json.dump(rec, open(path, "w"), indent=1)
 
