@@ -39,7 +39,7 @@ def worker(rank, world, port, out, mode):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     per = NCHAINS // world
-    sums, norm, nacc, extra = ob.run_many(job(ob, mode), rank * per, per, nthreads=2, mode=mode, extras=True)   # shard by global chain id
+    sums, norm, nacc, extra = ob.run_many(job(ob, mode), rank * per, per, nthreads=1 if world > 2 else 2, mode=mode, extras=True)   # shard by global chain id
     red = torch.from_numpy(reduction_vector(sums, norm, nacc, NSTEPS, extra))
     dist.all_reduce(red)                                                          # the one collective
     if rank == 0:
@@ -48,14 +48,16 @@ def worker(rank, world, port, out, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["fast", "cluster"])
-def test_two_rank_merge_equals_single_process(tmp_path, oracle, mode):
+@pytest.mark.parametrize("mode,world", [("fast", 2), ("cluster", 2), ("fast", 8)])
+def test_two_rank_merge_equals_single_process(tmp_path, oracle, mode, world):
+    """world = 8: the rank count of the driver's scaling run (the only one that matters; it cannot be rehearsed on one GPU --
+    the pool allows six GPU processes per card -- so the eight-rank rendezvous and merge are rehearsed here, on the CPU)."""
     import polymer_stats_amd as ps
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "red.npy")
-    mp.spawn(worker, args=(2, port, out, mode), nprocs=2, join=True)
+    mp.spawn(worker, args=(world, port, out, mode), nprocs=world, join=True)
     merged = np.load(out)
     sums, norm, nacc, extra = oracle.run_many(job(oracle, mode), 0, NCHAINS, nthreads=4, mode=mode, extras=True)
     single = reduction_vector(sums, norm, nacc, NSTEPS, extra)

@@ -120,3 +120,79 @@ def test_phase_scan_two_ranks_equal_one_rank_with_all_the_chains(tmp_path, main)
         if __import__("polymer_stats_amd")._lib.load().pstat_device_count() == 1:
             over, _ = _scan(tmp_path, "over.csv", "--gpus", "2", "--backend", "nccl", "--chains", "64", *common, timeout=300)
             assert over.returncode != 0 and "only 1 GPU(s) visible" in over.stderr
+
+
+SIX = 4      # ranks of the GPU-box rehearsals: the pool allows six processes on one card and the test runner, which has used
+             # the GPU in earlier tests, is one of them (six ranks + the runner were killed by the process guard).  The
+             # eight-rank rendezvous, launcher and merge are rehearsed on the CPU (tests/test_dist_gloo.py, tests/test_host.py)
+
+
+def test_bench_four_ranks_pool_the_chains_of_one_rank(tmp_path):
+    """`bench.py --gpus 4 --backend gloo` from a bare shell: four children on one port (all on device 0), ONE JSON line; its
+    pooled check values equal those of a single rank holding all 4 x 1024 chains (chains are identified by global id)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--backend", "gloo", "--steps", "2", "--warmup", "1", "--mc-steps", "500", "--no-cpu-baseline", "--no-fast-path",
+              "--no-rng-named", "--no-configs"]
+    six = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(SIX), "--chains", "1024", *common],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert six.returncode == 0, six.stderr[-3000:]
+    lines = [l for l in six.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, six.stdout
+    d6 = json.loads(lines[0])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--chains", str(SIX * 1024), *common],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads(one.stdout.strip())
+    assert d6["n_gpus"] == SIX and d6["check"]["chains_pooled"] == SIX * 1024 == d1["check"]["chains_pooled"]
+    for k in ("r3", "p3", "U", "AR", "r3_stderr"):
+        assert d6["check"][k] == pytest.approx(d1["check"][k], rel=1e-11, abs=1e-12), k
+    assert d6["value"] == pytest.approx(SIX * 1024 * 500 * 2 / (d6["ms_per_step"] * 2e-3), rel=1e-6)
+
+
+def test_phase_scan_four_ranks_equal_one_rank(tmp_path):
+    """BASELINE configs[4]'s workflow with four ranks (one port, all on device 0): the CSV equals the single-rank scan holding
+    all the chains to 1e-11."""
+    common = ["--main", "fixed-force", "--energy", "Ising", "--precision", "f64"]
+    six, out6 = _scan(tmp_path, "six.csv", "--gpus", str(SIX), "--backend", "gloo", "--chains", "16", *common)
+    assert six.returncode == 0, six.stderr[-3000:]
+    assert f"{SIX} rank(s) [gloo]" in six.stderr
+    one, out1 = _scan(tmp_path, "one.csv", "--chains", str(16 * SIX), *common)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a = np.loadtxt(out1, delimiter=",", skiprows=1)
+    b = np.loadtxt(out6, delimiter=",", skiprows=1)
+    assert a.shape == b.shape == (8, 12) and np.all(b[:, 2] == 16 * SIX)
+    np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-12)
+
+
+def test_bench_line_carries_one_measured_entry_per_baseline_config(tmp_path):
+    """The default bench line's `configs` array (rank 0 at N = 1): C1..C5 in f64 at BASELINE.json's sizes, each with its
+    kernel, rate, roofline fraction and both CPU baselines (oracle faithful and fast) -- the headline keys untouched."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--mc-steps", "3000",
+                        "--chains", "4096", "--cpu-seconds", "0.5", "--config-cpu-seconds", "0.2", "--no-fast-path", "--no-rng-named"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["cpu_baseline"]["kind"] == "port"
+    cfgs = d["configs"]
+    assert [c["id"] for c in cfgs] == ["C1", "C2", "C3", "C4", "C5"]
+    kernels = {"C1": "sweep_kernel<double>", "C2": "state in L2", "C3": "state in L2", "C4": "interacting_kernel<double>", "C5": "state in L2"}
+    for c in cfgs:
+        assert kernels[c["id"]] in c["kernel"] and c["dtype"] == "f64" and c["value"] > 0 and c["kernel_ms"] > 0
+        rf = c["roofline"]
+        assert 0 < rf["frac"] < 1 and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and rf["unit"] in ("GB/s", "TFLOP/s")
+        cb = c["cpu_baseline"]
+        assert cb["cores"] >= 1 and cb["faithful"]["value"] > 0 and cb["fast"]["value"] > 0
+        assert cb["gpu_over_faithful"] == pytest.approx(c["value"] / cb["faithful"]["value"])
+        assert c["check"]["chains_collapsed"] >= 0
+    c4 = cfgs[3]
+    assert c4["roofline"]["unit"] == "TFLOP/s" and c4["chains"] == 16384 and c4["n"] == 64 and c4["mc_steps"] == 20000
+    assert cfgs[4]["chains"] == 546 * 128 and cfgs[4]["n"] == 200
+    assert cfgs[1]["cpu_baseline"]["faithful"]["value"] == d["cpu_baseline"]["value"]       # C2 = the headline's own sample

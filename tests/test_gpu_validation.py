@@ -154,13 +154,20 @@ def test_config4_as_stated_f32_against_f64(ps):
 def test_config4_as_stated_f64_against_the_oracle_in_distribution(ps, oracle):
     """BASELINE configs[3] as stated, f64 kernel against the oracle's literal O(n^2) mode as two independent samples.
     On collapsed chains a 1e-15 rounding of a position can flip a decision (the trajectory fuzz), so bit
-    parity is not the right question there; equality in distribution is: <r>, <r_j^2>, <p>, AR within 5 sigma."""
+    parity is not the right question there; equality in distribution is: <r>, <r_j^2>, <p>, AR within 5 sigma.
+
+    The ENERGY observable (the pair sum of inc/eap_chain.jl:200-207 is what this configuration exists for): the pooled mean
+    of U is dominated by the 1/r^3 tail of a few collapsed chains (its standard error is as large as the mean), so the
+    comparison is made on a robust statistic -- the quartiles of the per-chain running mean <U> over the 16 384 device
+    chains (pstat_chain_means) against the 192 oracle chains, each within 5 standard errors of a sample quantile,
+    sqrt(p (1 - p) / N) / f(q_p), with the density f read off the large device sample."""
     nsteps = 20000
     op, pp = both(nsteps, num_chains=16384, precision=ps.F64, n=64, E0=1.0, K1=1.0, K2=0.0, Fz=0.5,
                   energy_type=ps.INTERACTING, seed=61)
     with ps.Ensemble(pp) as e:
         e.advance(nsteps)
         s = e.summary()
+        u_dev = e.chain_means()[14]                 # per-chain <U> (row 14 = U of the reduction vector's observables)
     osums, onorm, onacc = oracle.run_many(op, 9_000_000, 192, nthreads=16, mode="faithful")
     o_avg, o_se = pooled(osums, onorm)
     for k in (0, 1, 2, 3, 4, 5, 7, 8, 9):
@@ -168,6 +175,16 @@ def test_config4_as_stated_f64_against_the_oracle_in_distribution(ps, oracle):
         assert abs(z) < 5.0, (ps.OBS_NAMES[k], s.avg[k], o_avg[k], z)
     o_ar = onacc / nsteps
     assert abs(s.acceptance_ratio - o_ar.mean()) < 5 * np.hypot(s.ar_stderr, o_ar.std(ddof=1) / np.sqrt(len(o_ar)))
+    u_orc = osums[:, 14] / onorm
+    assert np.all(np.isfinite(u_dev)) and np.all(np.isfinite(u_orc))
+    assert np.median(u_dev) < -100.0              # the pair energy dominates: non-interacting chains hold U ~ -30 here
+    for p in (0.25, 0.5, 0.75):
+        h = 0.05
+        q_dev, q_orc = np.quantile(u_dev, p), np.quantile(u_orc, p)
+        f = 2 * h / (np.quantile(u_dev, p + h) - np.quantile(u_dev, p - h))          # density of per-chain <U> at the quantile
+        se = np.sqrt(p * (1 - p)) / f * np.sqrt(1.0 / len(u_dev) + 1.0 / len(u_orc))
+        assert abs(q_dev - q_orc) < 5.0 * se, (p, q_dev, q_orc, se)
+        assert se < 0.25 * abs(q_dev), (p, q_dev, se)   # the comparison has teeth: a quartile is known to better than 25 %
 
 
 def test_f64_state_in_memory_matches_state_in_lds(ps, monkeypatch):

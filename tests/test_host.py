@@ -220,15 +220,25 @@ def test_rank_launcher_stops_the_survivors_when_a_rank_fails(tmp_path):
     script.write_text(
         "import os, sys, time\n"
         "r = int(os.environ['RANK']); mode = sys.argv[1]\n"
-        "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert os.environ['WORLD_SIZE'] in ('3', '8') and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert os.environ['LOCAL_RANK'] == os.environ['RANK'] and int(os.environ['MASTER_PORT']) > 0\n"
         "if mode == 'fail' and r == 1: sys.exit(7)\n"
-        "if mode == 'fail': time.sleep(600)\n"
+        "if mode == 'killed' and r == 5: time.sleep(1.0); os.kill(os.getpid(), 9)\n"
+        "if mode in ('fail', 'killed'): time.sleep(600)\n"
         "print('hello from', r)\n")
-    drv = ("import sys; sys.path.insert(0, %r); from rank_spawn import spawn_ranks; rc, out = spawn_ranks(%r, [sys.argv[1]], 3); "
+    drv = ("import sys; sys.path.insert(0, %r); from rank_spawn import spawn_ranks; rc, out = spawn_ranks(%r, [sys.argv[1]], int(sys.argv[2])); "
            "sys.stdout.write(out); sys.exit(rc)") % (os.path.join(ROOT, "tools"), str(script))
-    ok = subprocess.run([sys.executable, "-c", drv, "ok"], capture_output=True, text=True, timeout=60)
+    ok = subprocess.run([sys.executable, "-c", drv, "ok", "3"], capture_output=True, text=True, timeout=60)
     assert ok.returncode == 0 and ok.stdout == "hello from 0\n" and "hello from 2" in ok.stderr
     t0 = time.time()
-    bad = subprocess.run([sys.executable, "-c", drv, "fail"], capture_output=True, text=True, timeout=60)
+    bad = subprocess.run([sys.executable, "-c", drv, "fail", "3"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and bad.stdout == "" and "rank 1 exited with code 7" in bad.stderr
     assert time.time() - t0 < 30          # did not sit out the survivors' 600 s
+    # eight ranks -- the driver's scaling run: one port, rank 0's stdout relayed, the others' on stderr; and a rank KILLED
+    # mid-run (signal, not an exit code) stops the other seven promptly
+    ok8 = subprocess.run([sys.executable, "-c", drv, "ok", "8"], capture_output=True, text=True, timeout=60)
+    assert ok8.returncode == 0 and ok8.stdout == "hello from 0\n" and all(f"hello from {r}" in ok8.stderr for r in range(1, 8))
+    t0 = time.time()
+    k8 = subprocess.run([sys.executable, "-c", drv, "killed", "8"], capture_output=True, text=True, timeout=60)
+    assert k8.returncode == 1 and k8.stdout == "" and "rank 5 exited with code -9" in k8.stderr
+    assert time.time() - t0 < 15
