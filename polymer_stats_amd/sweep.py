@@ -10,7 +10,15 @@ then reads the values back out of the file NAMES and the stdout lines.
 Here the cases of a sweep that share everything but their physics scalars become ONE ensemble (`pstat_create` with
 ncases > 1) and one launch per stage of the main's protocol -- the hosts' own `mcmc_cases` / `run_cases`, which the command
 line calls with one case --; cases are dealt to ranks round-robin (independent work, no exchange: `pmap`'s own partitioning),
-and every case's `.out` holds exactly the lines the single-case host prints for the same options, seed and chains.
+and every case's `.out` holds the lines the single-case host prints for the same options, seed and chains.
+
+What "the same" means: a chain's TRAJECTORY depends on its (seed, chain id) and its case's options only -- in f64 bit for bit
+whatever else shares the ensemble, however many ranks there are and whatever is already finished.  The printed f64 averages
+agree to ~1e-10 relative, not to the last bit: how a launch is cut into time segments (and, in f32, where the chains live)
+depends on how many chains are co-batched, and the running sums are folded in 128-step blocks that start at segment
+boundaries (the f64 clustering main also re-derives its cached n-hat there).  f32 / q16 cases are statistically equivalent
+across partitions, not trajectory-identical, once an ensemble is large enough to change the kernel's home
+(tests/test_gpu_sweep.py::test_a_case_does_not_depend_on_what_shares_its_ensemble_even_past_the_resident_slots).
 
     python tools/run_sweep.py WORKDIR --main mcmc_clustering_eap_chain --num-chains 64 \
         --axis run=1:5 --axis kT='10^(-2:0.2:2)' --axis E0=0:0.2:5 --axis K1=1 --axis K2=0 --axis Fz=0 --axis Fx=0 \

@@ -175,3 +175,33 @@ def test_cli_explicit_case_list_one_chain_per_case_and_options(tmp_path):
     # an option the main does not have is the main's own parser error, before anything runs
     bad = subprocess.run(cmd[:-2] + ["--no-such-option", "1"], capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "no-such-option" in bad.stderr
+
+
+def test_a_case_does_not_depend_on_what_shares_its_ensemble_even_past_the_resident_slots():
+    """What INTEGRATION.md 3a promises about co-batching, at the size where it gets hard: 1 300 cases x 64 chains are more
+    chain blocks than the chip has resident workgroups, so pstat_advance cuts the launch into time segments (and, for an
+    f32 sweep of many chains, may pick another state home) -- choices that depend on how many cases are co-batched.  Per
+    case: the f64 TRAJECTORIES (angles, generator, counters, step sizes) are identical whatever shares the ensemble; the
+    running sums of the f64 clustering main agree to ~1e-10 (its cached n-hat is mapped at a reflection and re-derived at
+    a segment boundary), those of the f64 sweep to rounding (1e-13: the 128-step blocks in which records are folded into
+    the sums start at the segment boundaries)."""
+    import polymer_stats_amd as ps
+    for main_kw, exact in ((dict(), True), (dict(move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, bend_mod=0.2), False)):
+        mk = lambda i: ps.default_params(n=48, E0=0.2 + 0.001 * i, K1=1.0, K2=0.1, Fz=0.3, kT=0.8 + 0.0005 * i, seed=70000 + i,
+                                         num_chains=64, precision=ps.F64, **main_kw)
+        big = [mk(i) for i in range(1300)]
+        with ps.Ensemble(big) as e:
+            info = e.launch_info()
+            assert info.blocks > info.blocks_per_cu * info.num_cus, (info.blocks, info.blocks_per_cu, info.num_cus)
+            e.advance(4400)
+            picked = {i: ([e.chain_state(i * 64 + k) for k in (0, 33, 63)], e.rolling(i)[0]) for i in (0, 649, 1299)}
+        for i, (states, avg) in picked.items():
+            with ps.Ensemble([mk(i), mk((i + 7) % 1300)]) as small:          # the same case in other company: one launch, one segment
+                small.advance(4400)
+                for k, a in zip((0, 33, 63), states):
+                    b = small.chain_state(k)
+                    for key in ("theta", "phi", "rng"):
+                        assert np.array_equal(a[key], b[key]), (i, k, key)
+                    assert a["nacc_total"] == b["nacc_total"] and a["phi_step"] == b["phi_step"]
+                    np.testing.assert_allclose(a["sums"], b["sums"], rtol=1e-13 if exact else 1e-10, atol=1e-9 if exact else 1e-8)
+                np.testing.assert_allclose(avg, small.rolling(0)[0], rtol=1e-10, atol=1e-10)
