@@ -92,11 +92,19 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def cpu_baseline_oracle():
+    """The CPU restatement of the reference (oracle/): loaded HERE and nowhere else in this file -- for the `cpu_baseline`
+    objects of the bench line (the headline's and the configs'), timed on the host cores beside the GPU numbers.  The
+    product path (polymer_stats_amd/, libpstat.so) never touches it (tests/test_abi.py)."""
+    from oracle import binding as ob
+    return ob
+
+
 def cpu_baseline(n, mc_steps, target_seconds=12.0):
     """Times the CPU restatement of the reference algorithm (oracle, faithful mode: deep copy +
     full recompute per step, fp64) on this host: one single-threaded chain per worker thread over all
     cores, like the reference's pmap farm.  Bounded sample of the same workload."""
-    from oracle import binding as ob
+    ob = cpu_baseline_oracle()
     cores = host_cores()
     P = ob.make_params(n=n, E0=1.0, K1=1.0, K2=0.0, kT=1.0, Fz=1.0, b=1.0, num_steps=mc_steps, seed=1, stepout=0)
     t0 = time.perf_counter()
@@ -142,9 +150,7 @@ def measure_configs(ps, torch, stream, pmc, headline, head_cpu, skip_cpu, budget
     from configs import config_list, F64_VECTOR_PEAK_TFLOPS
     out = []
     cores = host_cores()
-    ob = None
-    if not skip_cpu:
-        from oracle import binding as ob
+    ob = None if skip_cpu else cpu_baseline_oracle()
     for cfg in config_list(ps):
         t_cfg = time.perf_counter()
         entry = {"id": cfg["id"], "workload": cfg["workload"], "dtype": "f64"}

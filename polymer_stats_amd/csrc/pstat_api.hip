@@ -320,7 +320,15 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
     // `shape(packed)` prices the best lane count of one block layout with the makespan model of its kernel family;
     // packed blocks (run_job_queue<true>: a block holds `lanes` consecutive global chains, whichever cases they belong
     // to) are taken when they shorten the launch by more than 5 % -- an ensemble of 2 730 cases x 16 chains is 683 full
-    // waves instead of 2 730 quarter-filled ones.  Otherwise blocks stay inside a case and its scalars in SGPRs.
+    // waves instead of 2 730 quarter-filled ones: measured 2.3 x (non-interacting) and 2.5 x (Ising) on the f64 sweep.
+    // Otherwise blocks stay inside a case and its scalars in SGPRs.
+    // The clustering main packs only when the unpacked launch is at least four rounds of the resident slots deep.  Its
+    // step time is not uniform: a wave runs at the pace of its longest cluster, and across a phase grid that is 4.5 us
+    // per step for a disordered chain against 25-33 us for an aligned one (n = 100, tools/phase_latency.py).  A sweep
+    // that mixes them is paced by the sequential step time of its cold cases, not by throughput: there packing buys
+    // nothing and a 64-lane wave is a little slower than a 16-lane one (measured on run/K1_E0-kT-phase.jl's grid,
+    // 2 730 x 16 chains, 3e5 steps: 11.5 s unpacked, 13.0 s packed); only when workgroups queue several deep does the
+    // saved throughput win (all-cold 2 730 x 16: 676 -> 366 ms per 1e4 steps).
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, h->device));
     const int64_t per_case = h->base.num_chains, total = per_case * ncases;
@@ -392,7 +400,8 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
     if (ncases > 1 && supports_packed_cases(h->cfg)) {
       const Shape pk = shape(true);
       const char *pe = getenv("PSTAT_PACK");     // 0 | 1: tests and experiments
-      if (pe ? atoi(pe) != 0 : pk.cost < 0.95 * pick.cost) {
+      const bool worth = cluster_gm ? (pick.cost >= 4.0 && pk.cost < 0.5 * pick.cost) : pk.cost < 0.95 * pick.cost;
+      if (pe ? atoi(pe) != 0 : worth) {
         pick = pk;
         h->cfg.packed = 1;
         A.packed = 1;
