@@ -322,19 +322,22 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
     // to) are taken when they shorten the launch by more than 5 % -- an ensemble of 2 730 cases x 16 chains is 683 full
     // waves instead of 2 730 quarter-filled ones: measured 2.3 x (non-interacting) and 2.5 x (Ising) on the f64 sweep.
     // Otherwise blocks stay inside a case and its scalars in SGPRs.
-    // The clustering main packs only when the unpacked launch is at least four rounds of the resident slots deep.  Its
-    // step time is not uniform: a wave runs at the pace of its longest cluster, and across a phase grid that is 4.5 us
-    // per step for a disordered chain against 25-33 us for an aligned one (n = 100, tools/phase_latency.py).  A sweep
-    // that mixes them is paced by the sequential step time of its cold cases, not by throughput: there packing buys
-    // nothing and a 64-lane wave is a little slower than a 16-lane one (measured on run/K1_E0-kT-phase.jl's grid,
-    // 2 730 x 16 chains, 3e5 steps: 11.5 s unpacked, 13.0 s packed); only when workgroups queue several deep does the
-    // saved throughput win (all-cold 2 730 x 16: 676 -> 366 ms per 1e4 steps).
+    // The clustering main packs into waves no larger than a case's own chains would fill (16 lanes for cases of up to 16
+    // chains) unless the unpacked launch is at least four rounds of the resident slots deep.  Its step time is not
+    // uniform: a wave runs at the pace of its longest cluster, and across a phase grid that is 4.5 us per step for a
+    // disordered chain against 25-33 us for an aligned one (n = 100, tools/phase_latency.py).  A sweep that mixes them is
+    // paced by the sequential step time of its cold cases, not by throughput, and there a 64-lane wave of four cases is a
+    // little slower than four 16-lane waves (run/K1_E0-kT-phase.jl's grid, 2 730 x 16 chains, 3e5 steps: 11.5 s unpacked,
+    // 13.0 s packed four to a wave), while filling the idle lanes of a 16-lane wave with further cases is a gain throughout
+    // (2 730 x 5 chains: 1 012 -> 865 ms per 2e4 steps on the whole grid, 747 -> 353 on its cold part; 5 760 x 1 chain:
+    // 1.6-2.4 x); only when workgroups queue several deep does the throughput of full waves win (all-cold 2 730 x 16:
+    // 676 -> 366 ms per 1e4 steps).  profiles/r04/experiments/time_packed*.txt, twin.txt.
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, h->device));
     const int64_t per_case = h->base.num_chains, total = per_case * ncases;
     const char *le = getenv("PSTAT_LANES");
     struct Shape { int lanes; int64_t nblocks; double cost; };
-    auto shape = [&](const bool packed) -> Shape {
+    auto shape = [&](const bool packed, const bool deep) -> Shape {
       LaunchCfg cfg = h->cfg;
       cfg.packed = packed ? 1 : 0;
       auto wgs_of = [&](const int cand) -> int64_t {
@@ -355,7 +358,11 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
         int lds0 = 0, bpc = 0;
         if (kernel_info(cfg, h->args, &lds0, &bpc, nullptr) != hipSuccess || bpc < 1) bpc = 1;
         const double slots = (double)bpc * prop.multiProcessorCount;
-        for (int cand = 64; cand >= 16; cand >>= 1) {
+        // (packed, and the unpacked launch not many rounds deep: no wave larger than a case's chains rounded up to 16 / 32 / 64
+        // -- see the packing rule below)
+        int cmax = 64;
+        if (packed && !deep) cmax = per_case <= 16 ? 16 : (per_case <= 32 ? 32 : 64);
+        for (int cand = cmax; cand >= 16; cand >>= 1) {
           if (le && atoi(le) >= 1 && atoi(le) <= 64 && cand != atoi(le)) continue;
           double cost = (double)wgs_of(cand) / slots;
           if (cost < 1.0) cost = 1.0;
@@ -396,12 +403,11 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
       }
       return best;
     };
-    Shape pick = shape(false);
+    Shape pick = shape(false, false);
     if (ncases > 1 && supports_packed_cases(h->cfg)) {
-      const Shape pk = shape(true);
       const char *pe = getenv("PSTAT_PACK");     // 0 | 1: tests and experiments
-      const bool worth = cluster_gm ? (pick.cost >= 4.0 && pk.cost < 0.5 * pick.cost) : pk.cost < 0.95 * pick.cost;
-      if (pe ? atoi(pe) != 0 : worth) {
+      const Shape pk = shape(true, pick.cost >= 4.0 || (pe && atoi(pe) != 0));
+      if (pe ? atoi(pe) != 0 : pk.cost < 0.95 * pick.cost) {
         pick = pk;
         h->cfg.packed = 1;
         A.packed = 1;

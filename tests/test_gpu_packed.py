@@ -115,8 +115,11 @@ def test_pstat_create_packs_when_it_shortens_the_launch_and_only_then(ps, monkey
     grid = lambda m, nc, **kw: [P(kT=0.5 + 0.001 * i, num_chains=nc, seed=i, **kw) for i in range(m)]
     cl = dict(move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, energy_type=ps.ISING)
     with ps.Ensemble(grid(2730, 16, **cl)) as e:         # run/K1_E0-kT-phase.jl: 546 points x 5 runs, 16 chains each here: the
-        assert e.launch_info().packed_cases == 0         # clustering main is paced by its cold cases, not by throughput
-    with ps.Ensemble(grid(9000, 8, **cl)) as e:          # ... until workgroups queue many deep: 9 000 eighth-filled waves
+        assert e.launch_info().packed_cases == 0         # clustering main is paced by its cold cases: no four-case waves
+    with ps.Ensemble(grid(2730, 5, **cl)) as e:          # ... but the idle lanes of a 16-lane wave are filled with further cases
+        info = e.launch_info()
+        assert info.packed_cases == 1 and info.lanes_per_block == 16 and info.blocks == -(-2730 * 5 // 16)
+    with ps.Ensemble(grid(9000, 8, **cl)) as e:          # ... and full waves win once workgroups queue many deep
         info = e.launch_info()
         assert info.packed_cases == 1 and info.lanes_per_block == 64 and info.blocks == -(-9000 * 8 // 64)
     with ps.Ensemble(grid(546, 64, **cl)) as e:          # the phase scan: 64 chains per point divide the wave
