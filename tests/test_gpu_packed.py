@@ -149,3 +149,48 @@ def test_packed_f32_sweep_statistics_and_unpacked_agreement(ps, monkeypatch):
     for a, b in zip(out["0"][0], out["1"][0]):
         assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["phi"], b["phi"]) and a["nacc_total"] == b["nacc_total"]
     np.testing.assert_allclose(out["0"][1], out["1"][1], rtol=1e-5, atol=1e-4)
+
+
+def test_packed_handles_through_the_rest_of_the_abi(ps, oracle, monkeypatch):
+    """What else a host does with a batched handle, on packed blocks: re-initialisation between inits (fixed-force main),
+    a burn-in rung (pstat_scale_kT / reset_sampler / reset_averages) and a per-case pstat_set_kT (clustering main),
+    checkpoint + restore into a fresh packed handle, per-case reductions and pstat_chain_means -- each equal to the same
+    calls on unpacked handles, chain by chain."""
+    mk = lambda i, **kw: ps.default_params(n=50, E0=0.4 + 0.2 * i, K1=1.0, K2=0.1, Fz=0.1 * i, kT=0.7 + 0.1 * i, seed=4000 + i,
+                                           num_chains=12, precision=ps.F64, **kw)
+    results = {}
+    for pack in ("0", "1"):
+        monkeypatch.setenv("PSTAT_PACK", pack)
+        out = []
+        # fixed-force main: two inits with a Metropolis re-init between them, then checkpoint / restore
+        with ps.Ensemble([mk(i) for i in range(9)]) as e:
+            assert e.launch_info().packed_cases == int(pack)
+            e.advance(900)
+            e.reinit(False)
+            e.advance(400)
+            blob = e.checkpoint()
+            e.advance(300)
+            out.append([e.chain_state(c) for c in (0, 11, 12, 60, 107)])
+            out.append(np.array([e.reduce_host(i) for i in range(9)]))
+            out.append(e.chain_means(4))
+            with ps.Ensemble([mk(i) for i in range(9)]) as f:
+                f.restore(blob)
+                f.advance(300)
+                for c in (0, 11, 12, 60, 107):
+                    _state_equal(e.chain_state(c), f.chain_state(c), ("restore", pack, c))
+        # clustering main: one rung at 10 kT, back to kT, then case 3 alone at another temperature
+        cl = dict(move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, energy_type=ps.ISING)
+        with ps.Ensemble([mk(i, **cl) for i in range(9)]) as e:
+            assert e.launch_info().packed_cases == int(pack)
+            e.scale_kT(10.0); e.advance(300); e.reset_sampler(); e.reset_averages()
+            e.scale_kT(1.0); e.advance(500)
+            e.set_kT(2.5, icase=3); e.advance(300)
+            out.append([e.chain_state(c) for c in (0, 35, 36, 47, 48, 107)])
+            out.append(np.array([e.rolling(i)[0] for i in range(9)]))
+        results[pack] = out
+    a, b = results["0"], results["1"]
+    for x, y in zip(a[0] + a[3], b[0] + b[3]):
+        _state_equal(x, y, "packed vs unpacked")
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(a[4], b[4], rtol=1e-10, atol=1e-10)
