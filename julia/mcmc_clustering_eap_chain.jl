@@ -91,6 +91,7 @@ s = ArgParseSettings();
   "--devices";             arg_type = String;  default = "0"
   "--precision";           arg_type = String;  default = "f64";  help = "device arithmetic: f64 (the reference's Float64) | f32 (fast path) | q16"
   "--rng";                 arg_type = String;  default = "mwc64x"
+  "--uniform-bits";        arg_type = Int;     default = 0;   help = "random bits of the Metropolis draw rand(): 0 = the precision's default (53 for f64, like Julia's Float64 rand(); 23 for f32 / q16) | 23 | 53"
 end
 
 pargs = parse_args(s);
@@ -144,7 +145,7 @@ function params(pargs, num_chains, chain_id0, device, x0, dx0)
               pargs["bend-mod"], pargs["bend-angle"], pargs["cluster-prob"],
               uniform_x0 ? x0[1] : 0.0, uniform_x0 ? x0[2] : 0.0,
               isnothing(dx0) ? 2pi : dx0[1], isnothing(dx0) ? 0.1 : dx0[2],
-              uniform_x0 ? 1 : 0, 0, pargs["cutoff-radius"])
+              uniform_x0 ? 1 : 0, pargs["uniform-bits"], pargs["cutoff-radius"])
 end
 
 # --numeric-type (mcmc_eap_chain.jl:186-197): the per-chain sums are Float64 on the device (the reference's default);

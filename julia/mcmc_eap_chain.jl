@@ -92,6 +92,7 @@ s = ArgParseSettings();
   "--devices";             arg_type = String;  default = "0"
   "--precision";           arg_type = String;  default = "f64";  help = "device arithmetic: f64 (the reference's Float64) | f32 (fast path) | q16"
   "--rng";                 arg_type = String;  default = "mwc64x"
+  "--uniform-bits";        arg_type = Int;     default = 0;   help = "random bits of the Metropolis draw rand(): 0 = the precision's default (53 for f64, like Julia's Float64 rand(); 23 for f32 / q16) | 23 | 53"
   "--burn-in";             arg_type = Int;     default = 0
   "--burn-schedule";       arg_type = String;  default = "[1]"
 end
@@ -132,7 +133,7 @@ function params(pargs, num_chains, chain_id0, device)
               ct, et, pargs["do-flips"] ? 1 : 0, pargs["umbrella-sampling"] ? 1 : 0, prec, device, rng,
               0,                                   # move_set = PSTAT_MOVES_SINGLE: this main
               0.0, 0.0, 0.5, 0.0, 0.0, 2pi, 0.1,   # clustering-main options at their defaults (unused here)
-              0, 0, 7.5)
+              0, pargs["uniform-bits"], 7.5)
 end
 
 # --numeric-type (mcmc_eap_chain.jl:186-197): the per-chain sums are Float64 on the device (the reference's default);

@@ -79,6 +79,8 @@ def build_parser() -> argparse.ArgumentParser:
     a("--precision", dest="precision", type=str, default="f64",
       help="device arithmetic: f64 (the reference's Float64; default) | f32 (fast path: f32 state, f64 running sums; not for collapsed "
            "chains of the pair energies) | q16 (lattice angles, f32 arithmetic)")
+    a("--uniform-bits", dest="uniform-bits", type=int, default=0,
+      help="random bits of the Metropolis draw rand(): 0 = the precision's default (53 for f64, 23 for f32) | 23 | 53 (f64 only)")
     return p
 
 
@@ -157,6 +159,7 @@ def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int)
         steps_per_adjust=pargs["steps-per-adjust"], n=pargs["num-monomers"], num_chains=num_chains,
         seed=pargs["seed"], chain_id0=chain_id0, chain_type=ct, energy_type=et,
         umbrella=1 if pargs["umbrella-sampling"] else 0, precision=prec, device=device, rng=rng,
+        uniform_bits=int(pargs.get("uniform-bits", 0)),
         move_set=_lib.MOVES_CLUSTER, bend_mod=pargs["bend-mod"], bend_angle=pargs["bend-angle"],
         cluster_prob=pargs["cluster-prob"], cutoff_radius=pargs["cutoff-radius"], **x0kw)
 

@@ -6,7 +6,8 @@ reference's mcmc_eap_chain.jl, with the step loop running on the GPU through lib
 
 Same option names, short aliases, types and defaults as mcmc_eap_chain.jl:19-153; same files
 (<prefix>_trajectory.csv, <prefix>_rolling.csv: :256-259,329-348) and the same ten stdout lines
-(:386-395).  Options added by this implementation: --num-chains, --seed, --devices, --precision.
+(:386-395).  Options added by this implementation: --num-chains, --seed, --devices, --precision, --rng, --uniform-bits,
+--burn-in, --burn-schedule.
 `--num-chains C` runs C independent chains, each statistically one reference run with the given
 options, and pools them; everything the reference prints is then the pooled estimate.
 
@@ -88,6 +89,9 @@ def build_parser() -> argparse.ArgumentParser:
     a("--precision", dest="precision", type=str, default="f64",
       help="device arithmetic: f64 (the reference's Float64; default) | f32 (fast path: f32 state, f64 running sums; not for collapsed "
            "chains of the pair energies) | q16 (lattice angles, f32 arithmetic)")
+    a("--uniform-bits", dest="uniform-bits", type=int, default=0,
+      help="random bits of the Metropolis draw rand() (mcmc_eap_chain.jl:287): 0 = the precision's default (53 for f64, like "
+           "Julia's Float64 rand(); 23 for f32 / q16) | 23 | 53 (f64 only)")
     return p
 
 
@@ -155,7 +159,7 @@ def params_from_pargs(pargs: dict, num_chains: int, chain_id0: int, device: int)
         steps_per_adjust=pargs["steps-per-adjust"], n=pargs["num-monomers"], num_chains=num_chains,
         seed=pargs["seed"], chain_id0=chain_id0, chain_type=ct, energy_type=et,
         do_flips=1 if pargs["do-flips"] else 0, umbrella=1 if pargs["umbrella-sampling"] else 0,
-        precision=prec, device=device, rng=rng)
+        precision=prec, device=device, rng=rng, uniform_bits=int(pargs.get("uniform-bits", 0)))
 
 
 @dataclass

@@ -174,3 +174,26 @@ def test_plain_c_client_runs_the_ensemble(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "chains = 2048" in r.stdout and "steps = 30000" in r.stdout and "nan_rejects = 0" in r.stdout
+
+
+def test_cli_uniform_bits_option_reaches_the_device(tmp_path):
+    """--uniform-bits (ours, like --precision): 0 and 53 are the same f64 run; 23 is the f32-style Metropolis draw (the same
+    stream, so the same output unless an eps fell into [u, u + 2^-23)); 53 with --precision f32 is refused by pstat_create."""
+    from polymer_stats_amd import _lib, mcmc_clustering_eap_chain as chost, mcmc_eap_chain as host
+    outs = {}
+    for bits in ("0", "53", "23"):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            assert host.main(["-n", "16", "-e", "1.0", "-F", "0.4", "-N", "3000", "-v", "0", "--num-chains", "128", "--seed", "9",
+                              "--prefix", str(tmp_path / ("u" + bits)), "--uniform-bits", bits]) == 0
+        outs[bits] = buf.getvalue()
+    assert outs["0"] == outs["53"] and len(outs["23"].splitlines()) == 10
+    with pytest.raises(_lib.PstatError) as ei:
+        host.main(["-n", "16", "-N", "100", "-v", "0", "--num-chains", "64", "--prefix", str(tmp_path / "bad"), "--precision", "f32",
+                   "--uniform-bits", "53"])
+    assert "uniform_bits" in str(ei.value)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert chost.main(["-n", "16", "-e", "1.0", "-N", "800", "-v", "0", "--num-chains", "64", "--seed", "9",
+                           "--prefix", str(tmp_path / "c"), "--uniform-bits", "23"]) == 0
+    assert len(buf.getvalue().splitlines()) == 12
