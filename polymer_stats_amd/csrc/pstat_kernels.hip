@@ -199,6 +199,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   (void)Fx; (void)kT; (void)hb; (void)nbeta_log2e; (void)ising_scale;
 
   // ---- fill
+  R maxphi = 0;      // f64: the largest |phi| of the lane's chain as filled (chooses the step loop's sincos form, see below)
+  (void)maxphi;
   if constexpr (Q) {
     const uint16_t *gth = (const uint16_t *)S.ang, *gph = (const uint16_t *)S.ang + (int64_t)n * C;
 #pragma unroll 8
@@ -211,6 +213,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       R2 v;
       v.x = gth[(int64_t)i * C + c];
       v.y = gph[(int64_t)i * C + c];
+      if constexpr (sizeof(R) == 8) maxphi = fmax(maxphi, fabs(v.y));
       if (GM && i < A.lds_rows) reinterpret_cast<Cell *>(smem)[i * lanes + lane] = v;
       else if constexpr (GM) *reinterpret_cast<Cell *>(cells + ((EN == PSTAT_ISING && PSTAT_GI_CC) ? (uint32_t)lane * (uint32_t)n * (uint32_t)sizeof(Cell) + (uint32_t)i * (uint32_t)sizeof(Cell)
                                                                                                           : (uint32_t)(i * lanes + lane) * (uint32_t)sizeof(Cell))) = v;
@@ -415,6 +418,12 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
 
   if constexpr (sizeof(R) == 4) refresh_totals();
 
+  // The step loop, compiled twice for f64: with and without the huge-argument fold of the phi sincos (pstat_math.h,
+  // PSTAT_PHI_FOLD).  phi random-walks unwrapped by at most pi per step, so a wave none of whose chains can reach the bound
+  // within this segment runs the copy without it -- always, in practice; the other copy keeps any start (--x0) and any
+  // run length correct.
+  auto run_steps = [&](auto fold_tag) __attribute__((always_inline)) {
+  constexpr bool FOLD = decltype(fold_tag)::value;
   while (left > 0) {
     int chunk = left < FLUSH ? left : FLUSH;
     if (A.adaptive && to_adj < chunk) chunk = (int)to_adj;
@@ -481,7 +490,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
           // (each product passes through an opaque register, so no pass can fuse it into the sum that follows)
           auto rounded = [](R v) __attribute__((always_inline)) -> R { asm volatile("" : "+v"(v)); return v; };
           const R dphi = rounded(phistep * rounded(sym11<R>(d.wphi)));
-          const R dth = rounded(flip + rounded(thstep * rounded(sym11<R>(d.wth))));
+          R dth = rounded(thstep * rounded(sym11<R>(d.wth)));
+          if constexpr (RARE) dth = rounded(flip + dth);     // (x + 0 is not foldable under IEEE rules: -0 + 0 = +0; th0 + -0 = th0 + 0)
           ph1 = AG::wrap(ph0 + dphi);
           th1 = fmin(AG::theta_max, fmax((R)0, th0 + dth));
         } else {
@@ -497,8 +507,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
       R st0, ct0, sp0, cp0, st1, ct1, sp1, cp1;
       AG::sc_theta(th0, &st0, &ct0);
       AG::sc_theta(th1, &st1, &ct1);
-      AG::sc_phi(ph0, &sp0, &cp0);
-      AG::sc_phi(ph1, &sp1, &cp1);
+      AG::template sc_phi<FOLD>(ph0, &sp0, &cp0);
+      AG::template sc_phi<FOLD>(ph1, &sp1, &cp1);
       P dNxy, dMxy, D;   // old -> new differences of {n_x, n_y}, {mu_x, mu_y}, {n_z, mu_z}
       R dpair = 0;
       if constexpr (EN == PSTAT_ISING && sizeof(R) == 4) {
@@ -582,7 +592,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
             const bool has = side ? d.idx + 1 < (uint32_t)n : d.idx > 0;
             R sj, cj, spj, cpj, mjx, mjy, mjz;
             AG::sc_theta(aj.x, &sj, &cj);
-            AG::sc_phi(aj.y, &spj, &cpj);
+            AG::template sc_phi<FOLD>(aj.y, &spj, &cpj);
             const R njx = cpj * sj, njy = spj * sj, njz = cj;
             dipole<R, CT>(a_or_mu, k2e, njx, njy, njz, mjx, mjy, mjz);
             const R t0 = pair_term_fast(hb * (Nxy0.x + njx), hb * (Nxy0.y + njy), hb * (ct0 + njz),
@@ -801,6 +811,14 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
         stepv = P{thstep, phistep}; step3v = P{thstep3, phistep3};
       }
     }
+  }
+  };
+  if constexpr (sizeof(R) == 8) {
+    const bool can_reach = !((double)maxphi + 3.1416 * (double)remaining < PSTAT_PHI_FOLD);   // (also true for a NaN angle)
+    if (__builtin_amdgcn_ballot_w64(can_reach) != 0) run_steps(std::true_type{});
+    else run_steps(std::false_type{});
+  } else {
+    run_steps(std::false_type{});
   }
 
   // ---- spill

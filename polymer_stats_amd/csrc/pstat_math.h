@@ -93,7 +93,7 @@ __device__ __forceinline__ float bits24(uint32_t w) { return __uint_as_float(__b
 template <typename R>
 __device__ __forceinline__ R sym11(uint32_t w) {  // 2u - 1 in [-1,1)
   if constexpr (sizeof(R) == 4) return __uint_as_float(0x40000000u | (w >> 9)) - 3.0f;
-  else return (R)2 * ((R)(w >> 9) * (R)(1.0 / 8388608.0)) - (R)1;
+  else return __builtin_fma((R)(w >> 9), (R)(1.0 / 4194304.0), (R)-1);   // k 2^-22 - 1: every operation exact, = 2 u - 1
 }
 
 // The uniform eps of the Metropolis test (mcmc_eap_chain.jl:287: rand(), a Float64 with 53 random bits) under the two
@@ -333,10 +333,17 @@ __device__ __forceinline__ void sincos_f64(double x, double *s, double *c) {
 // running observables agree with the oracle's to ~1e-15 relative instead of bit for bit.
 // BOUNDED: the caller guarantees 0 <= x <= pi (theta after the clamp), no huge-argument fold is compiled in.
 // sin(0) = 0, sin(fl(pi)) = 1.2246e-16 and cos(fl(pi/2)) = 6.1e-17 exactly as sincos_f64 gives them.
-template <bool BOUNDED>
+// FOLD (unbounded arguments: phi random-walks unwrapped, inc/eap_chain.jl:232): arguments of |x| >= PSTAT_PHI_FOLD are first
+// folded by whole turns.  The two-word reduction below is good far beyond that (k HI is exact inside its fma and the
+// dropped third word contributes k * 1.5e-33: 1e-24 at |x| = 1e9; tools/mathcheck covers +-9e8), the bound only keeps k
+// inside an int32.  The fold is seven instructions that no chain ever needs (|phi| ~ pi sqrt(steps / 3)); the f64 sweep
+// therefore compiles its step loop twice and runs the FOLD = false copy whenever no chain of the wave can reach the
+// bound within the segment (run_segment: max |phi| at fill + pi per remaining step).
+#define PSTAT_PHI_FOLD 1.0e9
+template <bool BOUNDED, bool FOLD = true>
 __device__ __forceinline__ void sincos_fast_f64(double x, double *s, double *c) {
-  if constexpr (!BOUNDED) {
-    if (!(fabs(x) < 1.0e5)) {   // fold by whole turns: 2 pi = HI2 + LO2
+  if constexpr (!BOUNDED && FOLD) {
+    if (!(fabs(x) < PSTAT_PHI_FOLD)) {   // fold by whole turns: 2 pi = HI2 + LO2
       const double t = rint(x * 1.59154943091895345609e-01);
       x = __builtin_fma(-t, 2.44929359829470641435e-16, __builtin_fma(-t, 6.28318530717958623200e+00, x));
     }
@@ -350,6 +357,19 @@ __device__ __forceinline__ void sincos_fast_f64(double x, double *s, double *c) 
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
   const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2), S1);
   const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+  if constexpr (BOUNDED) {
+    // theta in [0, pi]: k is 0, 1 or 2 and sin(theta) >= 0, so the quadrant logic shrinks to two compares on k itself, an
+    // |.| and two negations (source modifiers) -- the same bits as the general form below gives on [0, pi]: there the sin
+    // kernel's sign is applied to r before the polynomial, here after it (an odd function of r, evaluated in the same
+    // operations), and for k = 0 the reduced r = theta is >= 0, for k = 2 it is theta - pi <= 0 (tools/mathcheck compares the two forms bit for bit).
+    const double ks = __builtin_fma(r * z, ps, r);
+    const double kc = __builtin_fma(z, __builtin_fma(z, pc, -0.5), 1.0);
+    const bool one = k == 1.0, two = k == 2.0;
+    const double cq = two ? -kc : kc;
+    *s = one ? kc : __builtin_fabs(ks);
+    *c = one ? -ks : cq;
+    return;
+  }
   // Quadrant q = k mod 4:  q  sin   cos     The sin kernel ks is odd in r, so its sign is applied to r BEFORE the
   //                        0  +ks   +kc     polynomial (one xor); kc's sign after it; then one swap.  Signs as
   //                        1  +kc   -ks     sign-bit masks straight from the bits of q: sign(kc) = bit 1 of q,
@@ -431,7 +451,8 @@ template <> struct Ang<double> {
   static __device__ __forceinline__ void sc(double x, double *s, double *c) { sincos_f64(x, s, c); }
   // the sweep's hot loop (see sincos_fast_f64): theta is clamped to [0, pi], phi random-walks
   static __device__ __forceinline__ void sc_theta(double x, double *s, double *c) { sincos_fast_f64<true>(x, s, c); }
-  static __device__ __forceinline__ void sc_phi(double x, double *s, double *c) { sincos_fast_f64<false>(x, s, c); }
+  template <bool FOLD = true>
+  static __device__ __forceinline__ void sc_phi(double x, double *s, double *c) { sincos_fast_f64<false, FOLD>(x, s, c); }
   static __device__ __forceinline__ double wrap(double x) { return x; }  // phi random-walks, eap_chain.jl:232
 };
 template <> struct Ang<float> {
@@ -442,6 +463,7 @@ template <> struct Ang<float> {
     *c = __builtin_amdgcn_cosf(x);
   }
   static __device__ __forceinline__ void sc_theta(float x, float *s, float *c) { sc(x, s, c); }
+  template <bool FOLD = true>
   static __device__ __forceinline__ void sc_phi(float x, float *s, float *c) { sc(x, s, c); }
   static __device__ __forceinline__ float wrap(float x) { return __builtin_amdgcn_fractf(x); }
 };

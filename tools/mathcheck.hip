@@ -23,9 +23,17 @@ __host__ __device__ inline double acos_arg(int i) {
 // argument of the rsqrt check: r^2 from 1e-12 to 1e+12, log-spaced with a per-point mantissa jitter
 __host__ __device__ inline double rsq_arg(int i) { return exp(-27.6 + 55.2 * ((double)(i & 0xFFFFF) + 0.5) / 1048576.0) * (1.0 + 1e-3 * (double)(i % 997)); }
 
+__device__ int g_form_mismatch = 0;   // arguments of [0, pi] on which the bounded hot-loop form and the general one differ in any bit
+
 __global__ void run(const double *x, double *s, double *c, double *ex, double *lg, double *sf, double *cf, double *ac, double *rq, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (x[i] >= 0.0 && x[i] <= M_PI) {
+    double s1, c1, s2, c2;
+    pstat::sincos_fast_f64<true>(x[i], &s1, &c1);
+    pstat::sincos_fast_f64<false>(x[i], &s2, &c2);
+    if (__double_as_longlong(s1) != __double_as_longlong(s2) || __double_as_longlong(c1) != __double_as_longlong(c2)) atomicAdd(&g_form_mismatch, 1);
+  }
   rq[i] = pstat::rsqrt_f64(rsq_arg(i));             // 1/r of the f64 pair terms
   pstat::sincos_f64(x[i], &s[i], &c[i]);
   if (x[i] >= 0.0 && x[i] <= M_PI) pstat::sincos_fast_f64<true>(x[i], &sf[i], &cf[i]);   // the sweep's hot-loop form
@@ -101,6 +109,10 @@ int main() {
   printf("acos_r (f64): max error %.3f ulp; acos(1) = %g, acos(-1) = %.17g\n", mac, ac[0], ac[1]);
   printf("fast hot-loop form: max error sin %.3f, cos %.3f (ulp of the result, or units of 2^-53 next to a zero); sin(fl(pi)) = %.17g, "
          "cos(fl(pi/2)) = %.17g, sin(0) = %g\n", msf, mcf, sf[1], cf[2], sf[0]);
+  int mism = -1;
+  if (hipMemcpyFromSymbol(&mism, HIP_SYMBOL(g_form_mismatch), sizeof mism) != hipSuccess) return 2;
+  printf("bounded hot-loop form against the general one on [0, pi]: %d arguments differ in some bit\n", mism);
+  if (mism != 0) bad += 1;
   printf("sin(fl(pi)) = %.17g (glibc %.17g)  cos(fl(pi/2)) = %.17g (glibc %.17g)  sin(0) = %g  log(0) = %g  log(1) = %g\n", s[1],
          std::sin(M_PI), c[2], std::cos(M_PI / 2), s[0], lg[0], lg[nsp - 1]);
   return bad ? 1 : 0;
