@@ -699,3 +699,24 @@ def test_f64_sweep_fuzz_over_both_state_homes(ps, oracle, monkeypatch):
                 assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step, ctx
                 np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-7, atol=1e-7, err_msg=str(ctx))
     assert min(homes.values()) > 20, homes
+
+
+@pytest.mark.parametrize("n", [30, 60], ids=["cells-in-lds", "cells-in-memory"])
+@pytest.mark.parametrize("x0_phi", [5.0e8, 3.0e9, -7.0e9], ids=["below-the-fold", "above", "far-below-zero"])
+def test_f64_bit_parity_with_huge_unwrapped_phi(ps, oracle, n, x0_phi):
+    """phi random-walks unwrapped (inc/eap_chain.jl:232).  The f64 sweep compiles its step loop twice: without the
+    huge-argument fold of the phi sincos (taken whenever no chain of the wave can reach |phi| = 1e9 within the segment --
+    always, in practice) and with it.  A start far out (the ABI's x0 start; the reference's --x0) drives both copies: the
+    trajectory still equals the oracle's, whose libm reduces such arguments exactly."""
+    kw = dict(n=n, E0=1.0, K1=1.0, K2=0.2, Fz=0.4, Fx=0.2, seed=23, use_x0=1, x0_phi=x0_phi, x0_theta=1.2, dx0_phi=3.0, dx0_theta=0.5)
+    op, pp = both(2500, num_chains=64, precision=ps.F64, **kw)
+    with ps.Ensemble(pp) as e:
+        e.advance(1300)
+        e.advance(1200)
+        for c in (0, 31, 63):
+            o = oracle.run(op, chain_id=c, mode="faithful", trace=True)
+            g = e.chain_state(c)
+            assert abs(g["phi"]).min() > 0.5 * abs(x0_phi)
+            assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (n, x0_phi, c)
+            assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total
+            np.testing.assert_allclose(e.microstate(c), np.r_[o.r, o.p, o.U], rtol=1e-7, atol=1e-7)

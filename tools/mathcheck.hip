@@ -55,8 +55,10 @@ int main() {
   std::vector<double> x(n);
   std::mt19937_64 g(7);
   // (beyond 1e5 the fold-by-turns path of sincos_f64 is only ~1e-11 accurate: not part of the 1-ulp claim)
-  std::uniform_real_distribution<double> th(0.0, M_PI), ph(-2000.0, 2000.0), big(-9.9e4, 9.9e4);
-  for (int i = 0; i < n; ++i) x[i] = i % 4 == 0 ? th(g) : (i % 4 == 1 ? ph(g) : (i % 4 == 2 ? big(g) : std::ldexp(th(g), -(i % 60))));
+  // (huge: up to the fold bound of the hot-loop form, PSTAT_PHI_FOLD = 1e9 -- its two-word reduction runs unfolded there)
+  std::uniform_real_distribution<double> th(0.0, M_PI), ph(-2000.0, 2000.0), big(-9.9e4, 9.9e4), huge(-9.0e8, 9.0e8);
+  for (int i = 0; i < n; ++i)
+    x[i] = i % 5 == 0 ? th(g) : (i % 5 == 1 ? ph(g) : (i % 5 == 2 ? big(g) : (i % 5 == 3 ? std::ldexp(th(g), -(i % 60)) : huge(g))));
   const double special[] = {0.0, M_PI, M_PI / 2, M_PI / 4, 3 * M_PI / 4, -M_PI, 2 * M_PI, 1e-300, 9e4, -7e4, std::nextafter(M_PI, 0.0), 1.0};
   const int nsp = (int)(sizeof special / sizeof *special);
   for (int i = 0; i < nsp; ++i) x[i] = special[i];
@@ -77,8 +79,10 @@ int main() {
   int bad = 0;
   for (int i = 0; i < n; ++i) {
     const double es = ulps(s[i], sinl((long double)x[i])), ec = ulps(c[i], cosl((long double)x[i]));
-    ms = fmax(ms, es); mc = fmax(mc, ec);
-    if (es > 1.0 || ec > 1.0) ++bad;
+    if (fabs(x[i]) < 1.0e5) {     // (sincos_f64 folds by whole turns beyond that: outside its 1-ulp claim)
+      ms = fmax(ms, es); mc = fmax(mc, ec);
+      if (es > 1.0 || ec > 1.0) ++bad;
+    }
     // fast form: judged in ulps of the result, except next to a zero of the function where its absolute error is what
     // matters (|r| rounding: 2^-53 |r|), i.e. in units of 2^-53 there
     const long double ws = sinl((long double)x[i]), wc = cosl((long double)x[i]);
@@ -100,9 +104,9 @@ int main() {
     const double a = fabs(x[i]);
     const double arg = -a * 0.007;                  // the same double the device saw
     const double ee = ulps(ex[i], expl((long double)arg));
-    me = fmax(me, ee);
+    if (a < 1.0e5) me = fmax(me, ee);
     if (a > 0) { const double el = ulps(lg[i], logl((long double)a)); ml = fmax(ml, el); if (el > 2.0) ++bad; }
-    if (ee > 2.0) ++bad;
+    if (ee > 2.0 && a < 1.0e5) ++bad;     // (beyond: exp underflows in double, not in the long-double reference)
   }
   printf("over %d arguments: max error sin %.3f ulp, cos %.3f ulp, exp %.3f ulp, log %.3f ulp; %d out of bounds\n", n, ms, mc, me, ml, bad);
   printf("rsqrt_f64 (v_rsq_f64 + one third-order correction): max error %.3f ulp\n", mrq);
