@@ -40,6 +40,9 @@
 
 #include <type_traits>
 
+// (the three-quadrant tail of the theta sincos pays in the sweep's step; here, where only sin(theta) of the old angle is kept,
+// it costs the register allocator 17 moves per step: the general tail stays)
+#define PSTAT_THETA_GENERIC_TAIL 1
 #include "pstat_cluster_common.h"
 #include "pstat_device.h"
 #include "pstat_math.h"

@@ -357,6 +357,7 @@ __device__ __forceinline__ void sincos_fast_f64(double x, double *s, double *c) 
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
   const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2), S1);
   const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+#ifndef PSTAT_THETA_GENERIC_TAIL
   if constexpr (BOUNDED) {
     // theta in [0, pi]: k is 0, 1 or 2 and sin(theta) >= 0, so the quadrant logic shrinks to two compares on k itself, an
     // |.| and two negations (source modifiers) -- the same bits as the general form below gives on [0, pi]: there the sin
@@ -370,6 +371,7 @@ __device__ __forceinline__ void sincos_fast_f64(double x, double *s, double *c) 
     *c = one ? -ks : cq;
     return;
   }
+#endif
   // Quadrant q = k mod 4:  q  sin   cos     The sin kernel ks is odd in r, so its sign is applied to r BEFORE the
   //                        0  +ks   +kc     polynomial (one xor); kc's sign after it; then one swap.  Signs as
   //                        1  +kc   -ks     sign-bit masks straight from the bits of q: sign(kc) = bit 1 of q,
