@@ -1,3 +1,6 @@
+# Ring depth of the in-memory clustering kernel on aligned (cold) chains (kernel experiments; profiles/r04/experiments/ab_cold.txt):
+#   for v in "d4 -DPSTAT_GM_D=4 -DPSTAT_GM_CAPT=10" "d6 -DPSTAT_GM_D=6 -DPSTAT_GM_CAPT=7" "prof -DPSTAT_GM_PROF"; do set -- $v; t=$1; shift;
+#     bash tools/build_variant.sh $t pstat_cluster_gm.hip pstat_cluster_gm.o -ffp-contract=fast "$@"; done
 set -e
 B=polymer_stats_amd/csrc/build
 for cfg in "E0=3 KT=0.1" "E0=1 KT=1"; do

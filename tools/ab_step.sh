@@ -1,4 +1,6 @@
-# A/B of the f64 sweep's step (kernel experiments): the library as built against a variant holding the previous pstat_sweep_f64g.o
+# A/B of the f64 sweep's step (kernel experiments; profiles/r04/experiments/ab_step.txt): the library as built against a variant
+# holding a pstat_sweep_f64g.o compiled from an earlier commit's csrc/ (git archive <commit> polymer_stats_amd/csrc include | tar -x -C /tmp/old;
+# hipcc ... -DPSTAT_PART=4 -c -o polymer_stats_amd/csrc/build/var_old/pstat_sweep_f64g.o /tmp/old/polymer_stats_amd/csrc/pstat_kernels.hip; link with the other objects)
 set -e
 V=polymer_stats_amd/csrc/build/var_old/libpstat.so
 for i in 1 2 3; do
