@@ -495,26 +495,31 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
 }
 
 // the persistent (block, segment) job loop of pstat_device.h around run_cluster_segment
-template <typename R, typename G, int CT, int EN, int ST>
+// (PACKED: chain blocks straddle cases, the case's scalars are per-lane values -- run_job_queue, pstat_device.h)
+template <typename R, typename G, int CT, int EN, int ST, bool PACKED>
 __global__ __launch_bounds__(64) void cluster_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ cases,
                                                      int umbrella, int *__restrict__ queue) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
-  run_job_queue(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len, int) {
+  run_job_queue<PACKED>(A, queue, lane, [&](const CaseConst &cc, int64_t chain, int64_t first, int64_t len, int) {
     run_cluster_segment<R, G, CT, EN, ST>(A, S, cc, umbrella, smem, lane, chain, first, len);
   }, cases);
 }
 
 using ClusterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int *);
 
-template <typename R, typename G, int ST>
-ClusterFn pick_ct_en(const LaunchCfg &cfg) {
+template <typename R, typename G, int ST, bool PACKED>
+ClusterFn pick_ct_en_p(const LaunchCfg &cfg) {
   const bool ising = cfg.energy_type == PSTAT_ISING;
   if (cfg.chain_type == PSTAT_DIELECTRIC)
-    return ising ? cluster_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_ISING, ST>
-                 : cluster_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING, ST>;
-  return ising ? cluster_kernel<R, G, PSTAT_POLAR, PSTAT_ISING, ST>
-               : cluster_kernel<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING, ST>;
+    return ising ? cluster_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_ISING, ST, PACKED>
+                 : cluster_kernel<R, G, PSTAT_DIELECTRIC, PSTAT_NONINTERACTING, ST, PACKED>;
+  return ising ? cluster_kernel<R, G, PSTAT_POLAR, PSTAT_ISING, ST, PACKED>
+               : cluster_kernel<R, G, PSTAT_POLAR, PSTAT_NONINTERACTING, ST, PACKED>;
+}
+template <typename R, typename G, int ST>
+ClusterFn pick_ct_en(const LaunchCfg &cfg) {
+  return cfg.packed ? pick_ct_en_p<R, G, ST, true>(cfg) : pick_ct_en_p<R, G, ST, false>(cfg);
 }
 
 }  // namespace
@@ -556,8 +561,9 @@ hipError_t cluster_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *ld
   if (e != hipSuccess) return e;
   if (lds_bytes) *lds_bytes = lds;
   if (blocks_per_cu) *blocks_per_cu = nb;
-  if (name) *name = cfg.precision == PSTAT_F64 ? "cluster_kernel<double>"
-                 : (cfg.precision == PSTAT_Q16 ? "cluster_kernel<float, q16 state>" : "cluster_kernel<float>");
+  if (name) *name = cfg.precision == PSTAT_F64 ? (cfg.packed ? "cluster_kernel<double> [packed cases]" : "cluster_kernel<double>")
+                 : (cfg.precision == PSTAT_Q16 ? (cfg.packed ? "cluster_kernel<float, q16 state> [packed cases]" : "cluster_kernel<float, q16 state>")
+                                               : (cfg.packed ? "cluster_kernel<float> [packed cases]" : "cluster_kernel<float>"));
   return hipSuccess;
 }
 

@@ -276,8 +276,7 @@ struct LaunchCfg {
   int state_global;  // f64 chain-per-lane kernels: state cells in the global working buffer (DevState::work) instead of LDS
   int packed;        // chain blocks straddle cases (SweepArgs::packed): the kernel instantiation with per-lane case scalars
 };
-// the chain-per-lane kernel of this configuration has a packed-cases instantiation (sweep: f32 and f64; clustering main:
-// the in-memory kernel, pstat_cluster_gm.hip)
+// the kernel of this configuration has a packed-cases instantiation (every chain-per-lane kernel; not the all-pairs ones)
 bool supports_packed_cases(const LaunchCfg &cfg);
 hipError_t launch_init(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
                        const CaseConst *cases, double phi_step, double theta_step,

@@ -1057,11 +1057,9 @@ static SweepFn pick_state() {
 }
 template <typename G, int CT, int EN>
 static SweepFn pick_flags(const LaunchCfg &cfg) {
-#if PSTAT_PART != 2
   // packed cases: ONE instantiation per (generator, chain, energy) -- the general one (Fx term and the rare options compiled
   // in, switched by their wave-uniform flags), which makes the same decisions as the specialised ones
   if (cfg.packed) return pick_state<G, CT, EN, true, true, true>();
-#endif
   const bool rare = cfg.do_flips || cfg.lag || cfg.umbrella;
   if (cfg.has_fx) return rare ? pick_state<G, CT, EN, true, true>() : pick_state<G, CT, EN, true, false>();
   return rare ? pick_state<G, CT, EN, false, true>() : pick_state<G, CT, EN, false, false>();
@@ -1125,9 +1123,8 @@ bool f64_state_global(const LaunchCfg &cfg, int64_t n, int64_t total_chains) {
 static int cell_bytes(int precision) { return precision == PSTAT_F64 ? 16 : (precision == PSTAT_Q16 ? 4 : 8); }
 
 bool supports_packed_cases(const LaunchCfg &cfg) {
-  if (cfg.energy_type != PSTAT_NONINTERACTING && cfg.energy_type != PSTAT_ISING) return false;   // all-pairs: a chain per wave
-  if (cfg.move_set == PSTAT_MOVES_CLUSTER) return cfg.state_global != 0;
-  return cfg.precision != PSTAT_Q16;
+  // every chain-per-lane kernel has a packed instantiation; the all-pairs energies run a chain per wavefront: nothing to pack
+  return cfg.energy_type == PSTAT_NONINTERACTING || cfg.energy_type == PSTAT_ISING;
 }
 
 int choose_lanes(int precision, int64_t n, int energy_type) {
@@ -1163,7 +1160,7 @@ hipError_t sweep_kernel_info(const LaunchCfg &cfg, const SweepArgs &a, int *lds_
   if (blocks_per_cu) *blocks_per_cu = nb;
   if (name) *name = cfg.precision == PSTAT_F64 ? (cfg.state_global ? (cfg.packed ? "sweep_kernel<double, state in L2> [packed cases]" : "sweep_kernel<double, state in L2>")
                                                                    : (cfg.packed ? "sweep_kernel<double> [packed cases]" : "sweep_kernel<double>"))
-                 : (cfg.precision == PSTAT_Q16 ? "sweep_kernel<float, q16 state>"
+                 : (cfg.precision == PSTAT_Q16 ? (cfg.packed ? "sweep_kernel<float, q16 state> [packed cases]" : "sweep_kernel<float, q16 state>")
                                                : (cfg.packed ? "sweep_kernel<float> [packed cases]" : "sweep_kernel<float>"));
   return hipSuccess;
 }

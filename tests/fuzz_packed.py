@@ -48,7 +48,8 @@ for trial in range(trials):
         cases.append((kw, cid))
     nsteps = int(rng.choice([400, 900, 1500]))
     os.environ["PSTAT_SEGMENTS"] = str(int(rng.choice([1, 2, 3])))
-    os.environ["PSTAT_F64_STATE"] = str(rng.choice(["lds", "global"])) if (not cluster and n <= 40) else "global"
+    # where the f64 state lives: the sweep's cells fit LDS up to n = 40; the clustering main has both homes at any n here
+    os.environ["PSTAT_F64_STATE"] = str(rng.choice(["lds", "global"])) if (cluster or n <= 40) else "global"
     params = []
     for kw, cid in cases:
         _, pp = both(nsteps, num_chains=nch, precision=ps.F64, chain_id0=cid, **common, **kw)

@@ -194,3 +194,53 @@ def test_packed_handles_through_the_rest_of_the_abi(ps, oracle, monkeypatch):
     np.testing.assert_allclose(a[1], b[1], rtol=1e-12, atol=1e-9)
     np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(a[4], b[4], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("prec", [0, 2], ids=["f32", "q16"])
+@pytest.mark.parametrize("main", ["sweep", "cluster"])
+def test_every_chain_per_lane_kernel_packs(ps, monkeypatch, prec, main):
+    """The f32 / q16 kernels (cells in LDS, LDS-sized workgroups of e.g. 51 lanes) pack too: the same chains, the same
+    trajectories as unpacked -- per chain their f32 arithmetic does not depend on what shares the wave."""
+    kw = dict(n=60, K1=1.0, K2=0.1, seed=7, num_chains=6, precision=prec)
+    if main == "cluster":
+        kw.update(move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, bend_mod=0.2)
+        monkeypatch.setenv("PSTAT_F32_STATE", "lds")
+    cases = [ps.default_params(E0=0.3 + 0.05 * i, Fz=0.02 * i, kT=0.8 + 0.01 * i, chain_id0=100 * i, **kw) for i in range(37)]
+    out = {}
+    for pack in ("0", "1"):
+        monkeypatch.setenv("PSTAT_PACK", pack)
+        with ps.Ensemble(cases) as e:
+            info = e.launch_info()
+            assert info.packed_cases == int(pack) and ("[packed cases]" in info.kernel.decode()) == (pack == "1")
+            assert "state in memory" not in info.kernel.decode()
+            e.advance(1500)
+            e.advance(700)
+            out[pack] = ([e.chain_state(c) for c in (0, 5, 6, 100, 221)], np.array([e.rolling(i)[0] for i in range(37)]))
+    for a, b in zip(out["0"][0], out["1"][0]):
+        assert np.array_equal(a["theta"], b["theta"]) and np.array_equal(a["phi"], b["phi"]) and np.array_equal(a["rng"], b["rng"])
+        assert a["nacc_total"] == b["nacc_total"] and a["phi_step"] == b["phi_step"]
+    np.testing.assert_allclose(out["0"][1], out["1"][1], rtol=2e-5, atol=2e-4)
+
+
+def test_packed_f64_cluster_with_cells_in_lds_against_the_oracle(ps, oracle, monkeypatch):
+    """The f64 clustering main's LDS home (the literal second witness of the variant tests) in packed blocks: bit parity."""
+    monkeypatch.setenv("PSTAT_F64_STATE", "lds")
+    monkeypatch.setenv("PSTAT_PACK", "1")
+    kws = [dict(n=20, E0=0.5 + 0.1 * i, K1=1.0, K2=0.1, Fz=0.1 * i, kT=0.9 + 0.05 * i, seed=60 + i, cluster_prob=0.5, bend_mod=0.3)
+           for i in range(9)]
+    params = []
+    for i, kw in enumerate(kws):
+        _, pp = both(1200, num_chains=7, precision=ps.F64, chain_id0=50 * i, **kw)
+        pp.move_set = ps.MOVES_CLUSTER
+        params.append(pp)
+    with ps.Ensemble(params) as e:
+        info = e.launch_info()
+        assert info.packed_cases == 1 and info.kernel.decode() == "cluster_kernel<double> [packed cases]"
+        e.advance(1200)
+        for i in (0, 4, 8):
+            op, _ = both(1200, **kws[i])
+            for k in (0, 6):
+                o = oracle.run(op, chain_id=50 * i + k, mode="cluster", trace=True)
+                g = e.chain_state(i * 7 + k)
+                assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), (i, k)
+                assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total
