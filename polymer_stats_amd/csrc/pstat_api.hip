@@ -359,7 +359,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
         if (kernel_info(cfg, h->args, &lds0, &bpc, nullptr) != hipSuccess || bpc < 1) bpc = 1;
         const double slots = (double)bpc * prop.multiProcessorCount;
         // (packed, and the unpacked launch not many rounds deep: no wave larger than a case's chains rounded up to 16 / 32 / 64
-        // -- see the packing rule below)
+        // -- the clustering main's packing rule, above)
         int cmax = 64;
         if (packed && !deep) cmax = per_case <= 16 ? 16 : (per_case <= 32 ? 32 : 64);
         for (int cand = cmax; cand >= 16; cand >>= 1) {
