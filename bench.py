@@ -203,7 +203,9 @@ def measure_configs(ps, torch, stream, pmc, headline, head_cpu, skip_cpu, budget
         else:
             entry["valu"] = None
         if ob is not None:
-            cb = {"cores": cores, "kind": "port", "unit": "MC monomer-updates/s"}
+            # (`options`: what the CPU sample ran -- for the C5 grid one representative point, the cost per update does not
+            # depend on the physics scalars)
+            cb = {"cores": cores, "kind": "port", "unit": "MC monomer-updates/s", "options": cfg["oracle"]}
             if cfg.get("headline") and head_cpu is not None:
                 cb["faithful"] = {"value": head_cpu["value"], "sample": head_cpu["sample"]}
             else:
