@@ -86,3 +86,26 @@ def test_throughput_floor(ps, name, floor, steps, kernel, kw):
     assert kernel in info.kernel.decode(), info.kernel.decode()
     assert rate > floor, f"{name}: {rate:.3e} per second, floor {floor:.1e} ({info.kernel.decode()}, " \
                          f"{info.lanes_per_block} lanes x {info.blocks_per_cu} workgroups per CU)"
+
+
+@pytest.mark.perf
+def test_packing_pays_where_it_is_chosen(ps, monkeypatch):
+    """2 730 cases x 16 chains of the fixed-force main: pstat_create packs four cases to a wave on its own, and the launch is
+    at least 1.6 x faster than with every workgroup inside one case (measured 2.25 x)."""
+    cases = [ps.default_params(n=100, E0=0.2 * (i // 21 % 26), K1=1.0, kT=10 ** (-2 + 0.2 * (i % 21)), num_chains=16, precision=1,
+                               seed=1000 + i) for i in range(2730)]
+    rate = {}
+    for pack in (None, "0"):
+        if pack is None:
+            monkeypatch.delenv("PSTAT_PACK", raising=False)
+        else:
+            monkeypatch.setenv("PSTAT_PACK", pack)
+        with ps.Ensemble(cases) as e:
+            assert e.launch_info().packed_cases == (1 if pack is None else 0)
+            e.advance(4000); e.sync()
+            best = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter(); e.advance(40000); e.sync()
+                best = min(best, time.perf_counter() - t0)
+            rate[pack] = 2730 * 16 * 40000 / best
+    assert rate[None] > 1.6 * rate["0"], rate
