@@ -73,6 +73,8 @@ namespace {
 
 // energies whose every step needs all n(n-1)/2 pairs: one chain per wavefront
 bool all_pairs(int energy_type) { return energy_type == PSTAT_INTERACTING || energy_type == PSTAT_CUTOFF; }
+// handles whose steps run one chain per wavefront (no chain blocks, no job queue)
+bool chain_per_wave(const pstat_handle *h) { return all_pairs(h->base.energy_type) || h->cfg.chain_wave != 0; }
 
 int alloc(pstat_handle *h, void **p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes);
@@ -270,9 +272,11 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
   for (auto &c : h->cases) any_fx = any_fx || c.Fx != 0.0;
   h->cfg = {h->base.precision, h->base.chain_type, h->base.energy_type, h->base.do_flips ? 1 : 0,
             h->base.umbrella ? 1 : 0, any_fx ? 1 : 0, 0, h->base.rng, h->base.move_set, 0};
-  h->cfg.state_global = f64_state_global(h->cfg, h->base.n, (int64_t)ncases * h->base.num_chains) ? 1 : 0;
+  h->cfg.chain_wave = cluster_chain_wave(h->cfg, h->base.n, h->base.num_chains, ncases) ? 1 : 0;
+  h->cfg.state_global = (!h->cfg.chain_wave && f64_state_global(h->cfg, h->base.n, (int64_t)ncases * h->base.num_chains)) ? 1 : 0;
 
-  const bool inter = all_pairs(h->base.energy_type);
+  // one chain per wavefront: the all-pairs energies, and the clustering main's small f64 ensembles (pstat_cluster_cw.hip)
+  const bool inter = chain_per_wave(h);
   int lanes = (inter || h->cfg.state_global) ? 64 : choose_lanes(h->base.precision, h->base.n, h->base.energy_type);
   if (lanes == 0) {
     delete h;
@@ -466,7 +470,7 @@ int pstat_create(const pstat_params *cases, int32_t ncases, void *stream, pstat_
                             hipMemcpyHostToDevice, h->stream));
   const InitOpts io{h->base.use_x0, h->base.x0_phi, h->base.x0_theta, h->base.dx0_phi, h->base.dx0_theta, nullptr};
   CREATE_HIP(launch_init(h->cfg, h->args, h->S, h->d_cases, h->base.phi_step, h->base.theta_step, io, h->stream));
-  if (inter) {  // a zero-step launch derives r, p, U (with the pair energy) from the fresh angles
+  if (all_pairs(h->base.energy_type)) {  // a zero-step launch derives r, p, U (with the pair energy) from the fresh angles
     h->args.nsteps = 0; h->args.step0 = 0;
     if (h->cfg.move_set == PSTAT_MOVES_CLUSTER)
       CREATE_HIP(launch_cluster_wave(h->cfg, h->args, h->S, h->d_cases, h->stream));
@@ -523,12 +527,14 @@ int pstat_advance(pstat_handle *h, int64_t nsteps) {
   if (rc) return rc;
   if (h->failed_job) return report_failed_job(h);
   const int64_t max_launch = 1ll << 30;  // per-launch step counters are 32-bit
-  if (all_pairs(h->base.energy_type)) {
+  if (chain_per_wave(h)) {
     while (nsteps > 0) {
       const int64_t len = nsteps < max_launch ? nsteps : max_launch;
       h->args.nsteps = len;
       h->args.step0 = h->step_in_init;
-      if (h->cfg.move_set == PSTAT_MOVES_CLUSTER)
+      if (h->cfg.chain_wave)
+        HIP_TRY(launch_cluster_cw(h->cfg, h->args, h->S, h->d_cases, h->stream));
+      else if (h->cfg.move_set == PSTAT_MOVES_CLUSTER)
         HIP_TRY(launch_cluster_wave(h->cfg, h->args, h->S, h->d_cases, h->stream));
       else
         HIP_TRY(launch_interacting(h->cfg, h->args, h->S, h->d_cases, 0, h->stream));
@@ -1013,15 +1019,16 @@ int pstat_launch_info_get(pstat_handle *h, pstat_launch_info *out) {
   std::memset(out, 0, sizeof *out);
   int lds = 0, bpc = 0;
   const char *name = "";
-  if (all_pairs(h->base.energy_type)) {
-    if (h->cfg.move_set == PSTAT_MOVES_CLUSTER) HIP_TRY(cluster_wave_kernel_info(h->cfg, h->base.n, &bpc, &name));
+  if (chain_per_wave(h)) {
+    if (h->cfg.chain_wave) HIP_TRY(cluster_cw_kernel_info(h->cfg, h->base.n, &bpc, &name));
+    else if (h->cfg.move_set == PSTAT_MOVES_CLUSTER) HIP_TRY(cluster_wave_kernel_info(h->cfg, h->base.n, &bpc, &name));
     else HIP_TRY(interacting_kernel_info(h->cfg, h->base.n, &bpc, &name));
   } else HIP_TRY(kernel_info(h->cfg, h->args, &lds, &bpc, &name));
   std::snprintf(out->kernel, sizeof out->kernel, "%s", name);
   out->lds_bytes = lds;
   out->threads_per_block = 64;
   out->lanes_per_block = h->args.lanes;
-  out->blocks = all_pairs(h->base.energy_type) ? h->S.C : h->args.nblocks;
+  out->blocks = chain_per_wave(h) ? h->S.C : h->args.nblocks;
   out->packed_cases = h->args.packed;
   out->blocks_per_cu = bpc;
   hipDeviceProp_t prop;

@@ -275,6 +275,7 @@ struct LaunchCfg {
   int move_set;  // PSTAT_MOVES_SINGLE (mcmc_eap_chain.jl) | PSTAT_MOVES_CLUSTER (mcmc_clustering_eap_chain.jl)
   int state_global;  // f64 chain-per-lane kernels: state cells in the global working buffer (DevState::work) instead of LDS
   int packed;        // chain blocks straddle cases (SweepArgs::packed): the kernel instantiation with per-lane case scalars
+  int chain_wave;    // clustering main, small f64 ensembles: one chain per wavefront (pstat_cluster_cw.hip, cluster_chain_wave())
 };
 // the kernel of this configuration has a packed-cases instantiation (every chain-per-lane kernel; not the all-pairs ones)
 bool supports_packed_cases(const LaunchCfg &cfg);
@@ -317,6 +318,11 @@ hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const De
 hipError_t launch_cluster_wave(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s, const CaseConst *cases,
                                hipStream_t stream);
 hipError_t cluster_wave_kernel_info(const LaunchCfg &cfg, int64_t n, int *blocks_per_cu, const char **name);
+// clustering main, non-interacting / Ising, f64, small ensembles: one chain per wavefront (pstat_cluster_cw.hip)
+bool cluster_chain_wave(const LaunchCfg &cfg, int64_t n, int64_t chains_per_case, int64_t ncases);
+hipError_t launch_cluster_cw(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s, const CaseConst *cases,
+                             hipStream_t stream);
+hipError_t cluster_cw_kernel_info(const LaunchCfg &cfg, int64_t n, int *blocks_per_cu, const char **name);
 hipError_t interacting_kernel_info(const LaunchCfg &cfg, int64_t n, int *blocks_per_cu, const char **name);
 
 }  // namespace pstat

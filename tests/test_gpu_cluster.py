@@ -26,18 +26,23 @@ def ps():
     return ps
 
 
-@pytest.fixture(params=["lds", "memory"])
+@pytest.fixture(params=["lds", "memory", "wave"])
 def f64_home(request, monkeypatch):
-    """Where the f64 chain-per-lane cluster kernel keeps a chain while a segment runs: (theta, phi) cells in LDS
-    (pstat_cluster.hip) or 40-byte cells with the reference's trigonometric cache in device memory
-    (pstat_cluster_gm.hip; the default).  Every f64 parity test below runs on both."""
-    monkeypatch.setenv("PSTAT_F64_STATE", "global" if request.param == "memory" else "lds")
+    """The three f64 kernels of the clustering main (non-interacting / Ising energies): one chain per lane with (theta, phi)
+    cells in LDS (pstat_cluster.hip) or 40-byte cells with the reference's trigonometric cache in device memory
+    (pstat_cluster_gm.hip; the default of large ensembles), and one chain per wavefront (pstat_cluster_cw.hip; the default
+    of small ones, MWC64X only).  Every f64 parity test below runs on all three."""
+    monkeypatch.setenv("PSTAT_F64_STATE", {"memory": "global", "lds": "lds", "wave": "wave"}[request.param])
     return request.param
 
 
 def _check_home(e, home):
     k = e.launch_info().kernel.decode()
-    if "cluster_kernel<double" in k and home is not None:
+    if home == "wave":
+        # (xoshiro128++ has no skip-ahead: those handles fall back to the chain-per-lane kernel; the all-pairs energies have
+        # their own chain-per-wavefront kernel)
+        assert "cluster_chain_wave_kernel" in k or e.cases[0].rng == 1 or "cluster_wave_kernel" in k, k
+    elif "cluster_kernel<double" in k and home is not None:
         assert ("state in memory" in k) == (home == "memory"), (k, home)
 
 
@@ -393,14 +398,20 @@ def test_f64_bit_parity_random_cluster_configurations(ps, oracle, f64_home):
     (200, dict(E0=0.6, K1=0.25, K2=0.0, Fz=0.0, kT=2.5, energy_type=2, adj_ub=0.40)),   # a point of run/K1_E0-kT-phase.jl's grid
     (41, dict(E0=1.0, mu=0.2, chain_type=1, Fz=0.4, Fx=0.3, energy_type=2, umbrella=1, rng=1)),
 ])
-def test_f64_cluster_long_chains_bit_parity_in_the_default_home(ps, oracle, n, kw):
-    """The chain lengths the reference's sweeps launch this main with (n = 100, 200) on the default home (device
-    memory): trajectories against the oracle's literal clustering main, 70 chains = one full and one
-    6-lane wave, a launch split included (weak coupling: no 1/r^3 collapse in 1200 steps)."""
+@pytest.mark.parametrize("forced", [None, "global"])
+def test_f64_cluster_long_chains_bit_parity_in_the_default_home(ps, oracle, monkeypatch, n, kw, forced):
+    """The chain lengths the reference's sweeps launch this main with (n = 100, 200) on the kernel pstat_create picks for a
+    small ensemble (one chain per wavefront; xoshiro128++ has no skip-ahead and stays with the chain-per-lane kernel in
+    device memory) and on the in-memory chain-per-lane kernel, the default of large ensembles: trajectories against the
+    oracle's literal clustering main, 70 chains = one full and one 6-lane wave there, a launch split included (weak coupling:
+    no 1/r^3 collapse in 1200 steps)."""
     nsteps = 1200
+    if forced:
+        monkeypatch.setenv("PSTAT_F64_STATE", forced)
     op, pp = _pair(ps, nsteps, 70, ps.F64, n=n, seed=71, cluster_prob=0.5, steps_per_adjust=400, **kw)
     with ps.Ensemble(pp) as e:
-        assert "state in memory" in e.launch_info().kernel.decode()
+        k = e.launch_info().kernel.decode()
+        assert ("cluster_chain_wave_kernel" in k) if (forced is None and not kw.get("rng")) else ("state in memory" in k), k
         e.advance(500); e.advance(nsteps - 500)
         e.sync()
         for c in (0, 1, 31, 63, 64, 69):
@@ -423,12 +434,13 @@ def test_f64_cluster_state_in_memory_matches_state_in_lds(ps, monkeypatch):
                dict(n=64, E0=1.0, K1=0.3, K2=0.05, Fz=0.3, Fx=0.2, energy_type=ps.ISING, cluster_prob=0.2),
                dict(n=33, E0=0.2, Fz=0.1, cluster_prob=0.1, use_x0=1, x0_phi=0.3, x0_theta=0.4, dx0_phi=0.05, dx0_theta=0.05)):
         res, blob = {}, None
-        for where in ("lds", "global"):
+        for where in ("lds", "global", "wave"):
             monkeypatch.setenv("PSTAT_F64_STATE", where)
             pp = ps.default_params(num_chains=200, precision=ps.F64, seed=78, steps_per_adjust=300,
                                    move_set=ps.MOVES_CLUSTER, **kw)
             with ps.Ensemble(pp) as e:
-                assert ("state in memory" in e.launch_info().kernel.decode()) == (where == "global")
+                k = e.launch_info().kernel.decode()
+                assert ("state in memory" in k) == (where == "global") and ("chain_wave" in k) == (where == "wave"), k
                 e.scale_kT(3.0); e.advance(400)
                 e.scale_kT(1.0); e.reset_sampler(); e.reset_averages()
                 e.advance(501)
@@ -438,17 +450,26 @@ def test_f64_cluster_state_in_memory_matches_state_in_lds(ps, monkeypatch):
                     e.restore(blob)          # the other variant's checkpoint: the layout is the angles-only one
                 e.advance(299)
                 res[where] = [e.chain_state(c) for c in (0, 63, 64, 199)] + [e.reduce_host()]
-        for x, y in zip(res["lds"][:-1], res["global"][:-1]):
-            for key in ("theta", "phi", "rng"):
-                assert np.array_equal(x[key], y[key]), (kw, key)
-            np.testing.assert_allclose(x["sums"], y["sums"], rtol=1e-10, atol=1e-8)
-            assert (x["nacc_total"], x["phi_step"], x["theta_step"]) == (y["nacc_total"], y["phi_step"], y["theta_step"])
-            np.testing.assert_allclose(x["normalizer"], y["normalizer"], rtol=1e-12)
-        np.testing.assert_allclose(res["lds"][-1], res["global"][-1], rtol=1e-10, atol=1e-8)
+        for other in ("global", "wave"):
+            for x, y in zip(res["lds"][:-1], res[other][:-1]):
+                for key in ("theta", "phi", "rng"):
+                    assert np.array_equal(x[key], y[key]), (kw, key, other)
+                np.testing.assert_allclose(x["sums"], y["sums"], rtol=1e-10, atol=1e-8)
+                assert (x["nacc_total"], x["phi_step"], x["theta_step"]) == (y["nacc_total"], y["phi_step"], y["theta_step"])
+                np.testing.assert_allclose(x["normalizer"], y["normalizer"], rtol=1e-12)
+            np.testing.assert_allclose(res["lds"][-1], res[other][-1], rtol=1e-10, atol=1e-8)
     monkeypatch.delenv("PSTAT_F64_STATE")
-    for n in (2, 40, 41):     # the default home is device memory at every chain length (the cache of n-hat pays everywhere)
-        with ps.Ensemble(ps.default_params(num_chains=64, precision=ps.F64, n=n, move_set=ps.MOVES_CLUSTER)) as e:
-            assert "state in memory" in e.launch_info().kernel.decode()
+    # defaults: a wave per chain for small ensembles and for sweeps of many small cases, the chain-per-lane kernel in device
+    # memory (at every chain length: the cache of n-hat pays everywhere) for large ensembles, xoshiro128++ and n > 256
+    P = lambda **kw: ps.default_params(precision=ps.F64, move_set=ps.MOVES_CLUSTER, **kw)
+    for cases, wave in (([P(num_chains=64, n=2)], True), ([P(num_chains=4096, n=41)], True), ([P(num_chains=4097, n=40)], False),
+                        ([P(num_chains=16, n=100, seed=i) for i in range(2730)], True),
+                        ([P(num_chains=16, n=200, seed=i) for i in range(2000)], False),
+                        ([P(num_chains=64, n=100, seed=i) for i in range(546)], False),
+                        ([P(num_chains=64, n=40, rng=1)], False), ([P(num_chains=64, n=257)], False)):
+        with ps.Ensemble(cases) as e:
+            k = e.launch_info().kernel.decode()
+            assert ("cluster_chain_wave_kernel" in k) == wave and ("state in memory" in k) == (not wave), (k, len(cases))
 
 
 @pytest.mark.parametrize("kw", [
@@ -456,24 +477,26 @@ def test_f64_cluster_state_in_memory_matches_state_in_lds(ps, monkeypatch):
     dict(n=100, E0=1.0, K1=0.3, K2=0.05, kT=0.05, energy_type=2, bend_mod=0.5, adj_ub=0.40),  # cold and stiff: clusters run on for tens of monomers
 ], ids=["disordered", "aligned"])
 def test_f64_cluster_homes_agree_at_scale(ps, monkeypatch, kw):
-    """Full-size ensembles of the two homes of the f64 cluster kernel under one protocol (annealing rung, then a recorded
+    """Full-size ensembles of the three f64 kernels of the clustering main under one protocol (annealing rung, then a recorded
     run): independent samples of the SAME algorithm, so every pooled average -- 16 observables, acceptance ratio, <cos^2>,
     <psi> -- must agree within 4.5 combined standard errors.  The aligned case drives what the bit-parity cases reach with
     a handful of chains only: the ring-fed growth beyond the window and the member passes of long clusters, on 16 384
     chains at once."""
     out = {}
-    for where in ("lds", "global"):
+    for where in ("lds", "global", "wave"):
         monkeypatch.setenv("PSTAT_F64_STATE", where)
         pp = ps.default_params(num_chains=16384, precision=ps.F64, seed=101 + len(out), move_set=ps.MOVES_CLUSTER,
                                cluster_prob=0.5, **kw)
         with ps.Ensemble(pp) as e:
-            assert ("state in memory" in e.launch_info().kernel.decode()) == (where == "global")
+            k = e.launch_info().kernel.decode()
+            assert ("state in memory" in k) == (where == "global") and ("chain_wave" in k) == (where == "wave"), k
             _run_gpu(e, pp, 12000, (10.0, 1.0), 4000)
             s = e.summary()
             assert s.nan_rejects == 0
             out[where] = (np.r_[s.avg, s.extra_avg, s.acceptance_ratio], np.r_[s.stderr, s.extra_stderr, s.ar_stderr])
-    z = (out["global"][0] - out["lds"][0]) / np.sqrt(out["global"][1] ** 2 + out["lds"][1] ** 2 + 1e-300)
-    assert np.all(np.abs(z) < 4.5), (z, out["global"][0], out["lds"][0])
+    for other in ("global", "wave"):
+        z = (out[other][0] - out["lds"][0]) / np.sqrt(out[other][1] ** 2 + out["lds"][1] ** 2 + 1e-300)
+        assert np.all(np.abs(z) < 4.5), (other, z, out[other][0], out["lds"][0])
 
 
 def test_f64_cluster_in_memory_equilibrium_without_flips(ps, golden):
@@ -501,6 +524,7 @@ def test_f64_cluster_in_memory_time_segments(ps, monkeypatch):
     pp = ps.default_params(num_chains=4096, precision=ps.F64, n=60, E0=1.0, K1=0.3, K2=0.05, Fz=0.4, seed=12, energy_type=ps.ISING,
                            move_set=ps.MOVES_CLUSTER, cluster_prob=0.4, bend_mod=0.3, steps_per_adjust=700)
     monkeypatch.setenv("PSTAT_MAX_SPINS", str(1 << 19))     # fail within ~1 s instead of hanging
+    monkeypatch.setenv("PSTAT_F64_STATE", "global")        # (an ensemble this small would run one chain per wavefront)
     states = {}
     for nseg in ("1", "3", "7"):
         monkeypatch.setenv("PSTAT_SEGMENTS", nseg)

@@ -114,6 +114,13 @@ def test_pstat_create_packs_when_it_shortens_the_launch_and_only_then(ps, monkey
     P = lambda **kw: ps.default_params(n=100, E0=1.0, K1=0.0, K2=1.0, precision=ps.F64, **kw)
     grid = lambda m, nc, **kw: [P(kT=0.5 + 0.001 * i, num_chains=nc, seed=i, **kw) for i in range(m)]
     cl = dict(move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, energy_type=ps.ISING)
+    # (sweeps of many small f64 cases run the clustering main one chain per wavefront, pstat_cluster_cw.hip: nothing to pack; the
+    # chain-per-lane kernel's own chooser is asked for below)
+    for m, nc in ((2730, 16), (2730, 5), (2730, 1)):
+        with ps.Ensemble(grid(m, nc, **cl)) as e:
+            info = e.launch_info()
+            assert info.packed_cases == 0 and info.blocks == m * nc and "cluster_chain_wave_kernel" in info.kernel.decode()
+    monkeypatch.setenv("PSTAT_F64_STATE", "global")
     with ps.Ensemble(grid(2730, 16, **cl)) as e:         # run/K1_E0-kT-phase.jl: 546 points x 5 runs, 16 chains each here: the
         assert e.launch_info().packed_cases == 0         # clustering main is paced by its cold cases: no four-case waves
     with ps.Ensemble(grid(2730, 5, **cl)) as e:          # ... but the idle lanes of a 16-lane wave are filled with further cases
@@ -124,6 +131,7 @@ def test_pstat_create_packs_when_it_shortens_the_launch_and_only_then(ps, monkey
         assert info.packed_cases == 1 and info.lanes_per_block == 64 and info.blocks == -(-9000 * 8 // 64)
     with ps.Ensemble(grid(546, 64, **cl)) as e:          # the phase scan: 64 chains per point divide the wave
         assert e.launch_info().packed_cases == 0
+    monkeypatch.delenv("PSTAT_F64_STATE")
     with ps.Ensemble(grid(3000, 16)) as e:               # fixed-force main, f64 cells in memory: 3 000 quarter waves > 1 024 slots
         info = e.launch_info()
         assert info.packed_cases == 1 and info.blocks == 750 and "state in L2" in info.kernel.decode()

@@ -292,7 +292,7 @@ def test_nonfinite_energy_counter_counts_every_such_proposal(ps, oracle, monkeyp
     kw = dict(n=n, E0=1.0, K1=0.8, K2=0.1, Fz=0.3, b=0.0, seed=5, energy_type=et, cutoff_radius=7.5)
     if moves:
         kw.update(cluster_prob=0.5, bend_mod=0.2)
-    homes = ("lds", "global") if (prec == 1 and et == 2) else ("default",)
+    homes = (("lds", "global", "wave") if moves else ("lds", "global")) if (prec == 1 and et == 2) else ("default",)
     for home in homes:
         if home != "default":
             monkeypatch.setenv("PSTAT_F64_STATE", home)
