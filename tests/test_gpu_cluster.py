@@ -563,3 +563,15 @@ def test_f32_cluster_homes_agree_at_scale_and_default_home(ps, monkeypatch):
     for n, chains, mem in ((200, 64, False), (200, 32768, False), (200, 65536, True), (100, 65536, False), (20, 131072, False)):
         with ps.Ensemble(ps.default_params(num_chains=chains, precision=ps.F32, n=n, move_set=ps.MOVES_CLUSTER)) as e:
             assert ("state in memory" in e.launch_info().kernel.decode()) == mem, (n, chains)
+
+
+def test_f64_chain_per_wavefront_kernel_fuzz(ps, monkeypatch):
+    """pstat_cluster_cw.hip over every chain length it takes (n = 2 ... 256: one, two and four monomers per lane and the
+    lengths either side of each boundary), hot to cold (aligned starts: clusters that run to the chain ends, one end drawing
+    alone for tens of rounds), both chain types, Ising and non-interacting, bending, umbrella, both eps contracts, a launch
+    split and an annealing rung in every run: 60 seeded configurations of tests/fuzz_cluster_wave.py (the long form: 600
+    more, profiles/r04/fuzz_cluster_wave.txt), three chains each bit-equal to the oracle."""
+    import fuzz_cluster_wave
+    monkeypatch.setenv("PSTAT_F64_STATE", "wave")      # (run() sets it too; restored by monkeypatch afterwards)
+    lines = []
+    assert fuzz_cluster_wave.run(60, 20261005, log=lambda *a: lines.append(" ".join(str(x) for x in a))) == 0, "\n".join(lines)
