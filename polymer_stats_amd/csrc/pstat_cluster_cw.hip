@@ -94,8 +94,23 @@ __device__ __forceinline__ double sum64(double v) {
   return (lane_value<double>(v, 0) + lane_value<double>(v, 16)) + (lane_value<double>(v, 32) + lane_value<double>(v, 48));
 }
 
+// The literal acceptance test of inc/acceptance.jl:29-39 with the Hastings ratio alpha = anum / aden and the cached log(alpha)
+// of the last acceptance: what metropolis_filter (pstat_math.h) evaluates for the one draw in ~1e3 that falls inside its
+// margin.  A function of its own, not inlined: its two dozen polynomial coefficients would otherwise be parked in scalar
+// registers across the whole step loop.
+__device__ __attribute__((noinline)) bool literal_accept(const double dU, const double kT, const double st1, const double st0,
+                                                         const double dw, const double anum, const double aden,
+                                                         const bool lag_pending, const double lag_num, const double lag_den,
+                                                         const double lag, const bool wide, const uint32_t weps, const uint32_t w0,
+                                                         const uint32_t wphi, const uint32_t wth) {
+  const double lg = lag_pending ? log_r(lag_num / lag_den) : lag;
+  const double delta = -dU / kT + log_r(st1 / st0) + dw + log_r(anum / aden) - lg;
+  const double eps = eps_uniform(wide, weps, w0, wphi, wth);
+  return (delta >= 0) || (eps < exp_r(delta));
+}
+
 #ifndef PSTAT_CW_WAVES
-#define PSTAT_CW_WAVES 3   // waves per SIMD asked of the register allocator
+#define PSTAT_CW_WAVES 4   // waves per SIMD asked of the register allocator (measured 2 / 3 / 4: 45 / 35 / 32 us per step of 43 680 chains, tools/ab_cw_waves.sh)
 #endif
 
 template <int CT, int EN, int M>
@@ -109,8 +124,8 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
   constexpr int NC = 64 * M;
   constexpr R PI = AG::theta_max;
   // cell of monomer k at entry k + 1; entries 0 and n + 1 are pads (a neighbour that does not exist: read, never used)
-  __shared__ double2 cA[NC + 2];      // (n_x, n_y)
-  __shared__ double2 cB[NC + 2];      // (n_z, theta)
+  __shared__ double2 cA[NC + 3];      // (n_x, n_y); entry NC + 2: the moved monomer BEFORE the move (the bonds before it read that)
+  __shared__ double2 cB[NC + 3];      // (n_z, theta)
   __shared__ double cP[NC + 2];       // phi
   __shared__ uint32_t draws[NPOS];
 
@@ -217,6 +232,7 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
 
   int64_t to_adj = A.adaptive ? A.steps_per_adjust - (A.step0 % A.steps_per_adjust) : 0;
   constexpr int FLUSH = 128;
+  const int sign_a = (lane & 7) == 5 ? (int)0x80000000 : 0, sign_b = (lane & 7) == 7 ? (int)0x80000000 : 0;
   int left = (int)A.nsteps;
   __builtin_amdgcn_wave_barrier();
 
@@ -273,6 +289,8 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
       if (lane == 0) {
         cA[idx + 1] = double2{n1.x, n1.y};
         cB[idx + 1] = double2{n1.z, th1};
+        cA[NC + 2] = a0;
+        cB[NC + 2] = b0;
       }
       __builtin_amdgcn_wave_barrier();
 
@@ -392,14 +410,14 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
       bool bond_on;
       {
         const int q = lane & 7;
-        const int ia = q < 2 ? idx - 1 : (q < 4 ? idx : (q < 6 ? upper : lower - 1));
-        const int ib = q < 2 ? idx : (q < 4 ? idx + 1 : (q < 6 ? upper + 1 : lower));
+        int ia = q < 2 ? idx - 1 : (q < 4 ? idx : (q < 6 ? upper : lower - 1));
+        int ib = q < 2 ? idx : (q < 4 ? idx + 1 : (q < 6 ? upper + 1 : lower));
+        ia = q == 2 ? NC + 1 : ia;           // the bonds before the move see the old monomer (entry NC + 2)
+        ib = q == 0 ? NC + 1 : ib;
         const double2 xa = cA[ia + 1], za = cB[ia + 1], xb = cA[ib + 1], zb = cB[ib + 1];
         T3 na{xa.x, xa.y, za.x}, nb{xb.x, xb.y, zb.x};
-        if (q == 0) nb = n0;                 // the bonds before the move see the old monomer
-        if (q == 2) na = n0;
-        na.z = q == 5 ? -na.z : na.z;        // refl_n!: n_z -> -n_z
-        nb.z = q == 7 ? -nb.z : nb.z;
+        na.z = __hiloint2double(__double2hiint(na.z) ^ sign_a, __double2loint(na.z));   // refl_n!: n_z -> -n_z (lanes 5: a, 7: b)
+        nb.z = __hiloint2double(__double2hiint(nb.z) ^ sign_b, __double2loint(nb.z));
         const T3 ma = mu_of(na), mb = mu_of(nb);
         const R dt = dot3(na, nb);
         // psi_j (inc/eap_chain.jl:45-47) feeds the bending energy and the <psi> averager: without stiffness (kappa = 0, every
@@ -447,10 +465,7 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
       const R dw = umb ? dus * wscale : (R)0;
       bool ok = metropolis_filter(dU * ninv_kT + (dw - (lag_pending ? (R)0 : lag)), (st1 * anum) * (lag_pending ? lag_den : (R)1),
                                   (st0 * aden) * (lag_pending ? lag_num : (R)1), weps, [&]() -> bool {
-        const R lg = lag_pending ? log_r(lag_num / lag_den) : lag;
-        const R delta = -dU / kT + log_r(st1 / st0) + dw + log_r(anum / aden) - lg;
-        const R eps = eps_uniform(A.wide_eps != 0, weps, w0, wphi, wth);
-        return (delta >= 0) || (eps < exp_r(delta));
+        return literal_accept(dU, kT, st1, st0, dw, anum, aden, lag_pending, lag_num, lag_den, lag, A.wide_eps != 0, weps, w0, wphi, wth);
       });
       ok = ok && !edge;
       ok = __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
