@@ -79,6 +79,13 @@ template <int CTRL> __device__ __forceinline__ double dpp_f64(const double v) {
   const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// b in the lanes of the constant mask, a elsewhere (the mask is an immediate of the scalar unit: no compare, no live register)
+__device__ __forceinline__ double sel_lanes(const double a, const double b, const uint64_t mask) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(a)), "v"(__double2loint(b)), "s"(mask));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(a)), "v"(__double2hiint(b)), "s"(mask));
+  return __hiloint2double(hi, lo);
+}
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
 // sum over the 8 lanes of an aligned group (every lane of the group ends with it)
 __device__ __forceinline__ double sum8(double v) {
@@ -92,6 +99,84 @@ __device__ __forceinline__ double sum64(double v) {
   v = sum8(v);
   v += dpp_f64<DPP_ROW_MIRROR>(v);
   return (lane_value<double>(v, 0) + lane_value<double>(v, 16)) + (lane_value<double>(v, 32) + lane_value<double>(v, 48));
+}
+
+// ---- Polynomial coefficients of the step's trigonometry, read from LDS where they are used.  A double constant cannot be an
+// operand of an f64 instruction: it is built in a register pair first -- by two vector moves if the instruction wants it as
+// its accumulator, which is what the Horner forms below compile to, or parked in scalar registers across the loop, which
+// spills the step's own scalars (the kernel needs ~60 such constants).  One broadcast ds_read_b128 delivers two coefficients
+// to where the fused multiply-add wants them and costs the vector ALU nothing.  The arithmetic is that of sincos_fast_f64
+// (general form), pair_term_fast and acos_r in pstat_math.h, operation for operation.
+enum { K_2OPI = 0, K_PIO2_HI, K_PIO2_MID, K_S6, K_S5, K_S4, K_S3, K_S2, K_S1, K_C6, K_C5, K_C4, K_C3, K_C2, K_C1, K_R375, K_M3, K_INV4PI,
+       K_A0, K_PIO2 = K_A0 + 13, K_PI, NK };
+__constant__ double KINIT[NK] = {
+    6.36619772367581382433e-01, 1.57079632679489655800e+00, 6.12323399573676603587e-17,
+    1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06, -1.98412698298579493134e-04,
+    8.33333333332248946124e-03, -1.66666666666666324348e-01,
+    -1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07, 2.48015872894767294178e-05,
+    -1.38888888888741095749e-03, 4.16666666666666019037e-02,
+    0.375, -3.0, 0.0795774715459476679,
+    2.87578513674215663354e-02, -1.48518870712472036977e-02, 1.74008794426940213707e-02, 5.45750671864035814818e-03,
+    1.03228143501857792808e-02, 1.14791774151849056834e-02, 1.39712129735529329289e-02, 1.73523927208699725588e-02,
+    2.23721729421498885526e-02, 3.03819441385312465076e-02, 4.46428571463554288434e-02, 7.49999999999843292020e-02,
+    1.66666666666666685170e-01,
+    1.57079632679489661923, 3.14159265358979323846};
+
+__device__ __forceinline__ void sincos_tab(double x, const double *kt, double *s, double *c) {
+  if (!(fabs(x) < PSTAT_PHI_FOLD)) {   // fold by whole turns (no chain gets here: see sincos_fast_f64)
+    const double t = rint(x * 1.59154943091895345609e-01);
+    x = __builtin_fma(-t, 2.44929359829470641435e-16, __builtin_fma(-t, 6.28318530717958623200e+00, x));
+  }
+  const double k = rint(x * kt[K_2OPI]);
+  const double r = __builtin_fma(-k, kt[K_PIO2_MID], __builtin_fma(-k, kt[K_PIO2_HI], x));
+  const double z = r * r;
+  const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, kt[K_S6], kt[K_S5]), kt[K_S4]), kt[K_S3]), kt[K_S2]), kt[K_S1]);
+  const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, kt[K_C6], kt[K_C5]), kt[K_C4]), kt[K_C3]), kt[K_C2]), kt[K_C1]);
+  const uint32_t q = (uint32_t)(int)k;
+  const uint32_t odd = q << 31;
+  const uint32_t m_kc = (q >> 1) << 31;
+  const uint32_t m_ks = m_kc ^ odd;
+  const double rs = __hiloint2double((int)(__double2hiint(r) ^ m_ks), __double2loint(r));
+  const double ks = __builtin_fma(rs * z, ps, rs);
+  const double kc0 = __builtin_fma(z, __builtin_fma(z, pc, -0.5), 1.0);
+  const double kc = __hiloint2double((int)(__double2hiint(kc0) ^ m_kc), __double2loint(kc0));
+  const bool swap = (int)odd < 0;
+  *s = swap ? kc : ks;
+  *c = swap ? ks : kc;
+}
+__device__ __forceinline__ double pair_term_tab(double rx, double ry, double rz, double mix, double miy, double miz, double mjx,
+                                                double mjy, double mjz, const double *kt) {
+  const double r2 = __builtin_fma(rz, rz, __builtin_fma(ry, ry, rx * rx));
+  const double y0 = __builtin_amdgcn_rsq(r2);
+  const double e = __builtin_fma(-(r2 * y0), y0, 1.0);
+  const double y = __builtin_fma(y0 * e, __builtin_fma(e, kt[K_R375], 0.5), y0);       // rsqrt_f64
+  const double ir2 = y * y;
+  const double mimj = __builtin_fma(miz, mjz, __builtin_fma(miy, mjy, mix * mjx));
+  const double mir = __builtin_fma(miz, rz, __builtin_fma(miy, ry, mix * rx));
+  const double mjr = __builtin_fma(mjz, rz, __builtin_fma(mjy, ry, mjx * rx));
+  const double num = __builtin_fma(kt[K_M3] * ir2, mir * mjr, mimj);
+  return num * (ir2 * y) * kt[K_INV4PI];
+}
+__device__ __forceinline__ double acos_tab(const double x, const double *kt) {
+  const double a = fabs(x);
+  const bool big = a >= 0.5;
+  const double z = big ? __builtin_fma(a, -0.5, 0.5) : a * a;
+  double p = kt[K_A0];
+#pragma unroll
+  for (int i = 1; i < 13; ++i) p = __builtin_fma(p, z, kt[K_A0 + i]);
+  const double zp = z * p;
+  const double y = __builtin_amdgcn_rsq(z);
+  const double s0 = z * y, h0 = 0.5 * y;
+  const double r = __builtin_fma(-s0, h0, 0.5);
+  const double s1 = __builtin_fma(s0, r, s0), h1 = __builtin_fma(h0, r, h0);
+  double sq = __builtin_fma(__builtin_fma(-s1, s1, z), h1, s1);
+  sq = z == 0.0 ? 0.0 : sq;
+  const double t = big ? sq : x;
+  const double as = __builtin_fma(t, zp, t);
+  const double small = kt[K_PIO2] - as;
+  const double two = as + as;
+  const double bigv = x < 0.0 ? kt[K_PI] - two : two;
+  return big ? bigv : small;
 }
 
 // The literal acceptance test of inc/acceptance.jl:29-39 with the Hastings ratio alpha = anum / aden and the cached log(alpha)
@@ -128,6 +213,7 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
   __shared__ double2 cB[NC + 3];      // (n_z, theta)
   __shared__ double cP[NC + 2];       // phi
   __shared__ uint32_t draws[NPOS];
+  __shared__ double KT[NK];
 
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
@@ -172,6 +258,7 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
         cA[k + 1] = double2{0, 0}; cB[k + 1] = double2{0, 0}; cP[k + 1] = 0;
       }
     }
+    if (lane < NK) KT[lane] = KINIT[lane];
     if (lane == 0) {
       cA[0] = double2{0, 0}; cB[0] = double2{0, 0}; cP[0] = 0;
       cA[NC + 1] = double2{0, 0}; cB[NC + 1] = double2{0, 0}; cP[NC + 1] = 0;
@@ -233,6 +320,10 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
   int64_t to_adj = A.adaptive ? A.steps_per_adjust - (A.step0 % A.steps_per_adjust) : 0;
   constexpr int FLUSH = 128;
   const int sign_a = (lane & 7) == 5 ? (int)0x80000000 : 0, sign_b = (lane & 7) == 7 ? (int)0x80000000 : 0;
+  const int bond_mu = ((lane & 6) == 4) ? -1 : 0, bond_ml = ((lane & 6) == 6) ? -1 : 0;      // lanes of the upper / lower boundary bond
+  const int bond_oa = ((lane & 7) < 2 || (lane & 7) >= 6) ? -1 : 0, bond_ob = ((lane & 7) >= 2 && (lane & 7) < 6) ? 1 : 0;
+  const int bond_olda = (lane & 7) == 2 ? -1 : 0, bond_oldb = (lane & 7) == 0 ? -1 : 0;
+  const int bond_sign = (lane & 1) ? 0 : (int)0x80000000;     // even lanes hold the bond BEFORE the proposal: subtracted
   int left = (int)A.nsteps;
   __builtin_amdgcn_wave_barrier();
 
@@ -252,6 +343,9 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
         for (int q = 0; q < WPL; ++q) draws[WPL * lane + q] = t.next();
       }
       __builtin_amdgcn_wave_barrier();
+      int kz = 0;
+      asm volatile("" : "+v"(kz));          // (the table is re-read every step, never held in registers across the loop)
+      const double *const kt = &KT[kz];
       const uint4 fixed = *reinterpret_cast<const uint4 *>(&draws[0]);
       const uint32_t w0 = __builtin_amdgcn_readfirstlane(fixed.x);
       const uint32_t wphi = __builtin_amdgcn_readfirstlane(fixed.y);
@@ -275,9 +369,9 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
       // three sincos in one instruction stream: lane 0 theta', lane 1 phi', lane 2 theta (the cell carries no sin(theta))
       R st1, ct1, sp1, cp1, st0;
       {
-        const R arg = lane == 1 ? ph1 : (lane == 2 ? th0 : th1);
+        const R arg = sel_lanes(sel_lanes(th1, ph1, 2ull), th0, 4ull);
         R sv, cv;
-        sincos_fast_f64<false, true>(arg, &sv, &cv);
+        sincos_tab(arg, kt, &sv, &cv);
         st1 = lane_value<R>(sv, 0); ct1 = lane_value<R>(cv, 0);
         sp1 = lane_value<R>(sv, 1); cp1 = lane_value<R>(cv, 1);
         st0 = lane_value<R>(sv, 2);
@@ -407,14 +501,15 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
       // eight lanes, group 1 its bending energies, group 2 its pair energies: the three differences come out of ONE tree.
       const bool on_u = flipped && upper < n - 1, on_l = flipped && lower > 0;
       R dpsi_all, dbend_all, dpair_all, new_upper_p, new_lower_p, bond_dt;
-      bool bond_on;
+      int bond_on;
       {
         const int q = lane & 7;
-        int ia = q < 2 ? idx - 1 : (q < 4 ? idx : (q < 6 ? upper : lower - 1));
-        int ib = q < 2 ? idx : (q < 4 ? idx + 1 : (q < 6 ? upper + 1 : lower));
-        ia = q == 2 ? NC + 1 : ia;           // the bonds before the move see the old monomer (entry NC + 2)
-        ib = q == 0 ? NC + 1 : ib;
-        const double2 xa = cA[ia + 1], za = cB[ia + 1], xb = cA[ib + 1], zb = cB[ib + 1];
+        // entries: (idx - 1, idx) (idx - 1, idx) (idx, idx + 1) (idx, idx + 1) (upper, upper + 1) x 2 (lower - 1, lower) x 2
+        const int ebase = (idx + 1) + ((upper - idx) & bond_mu) + ((lower - idx) & bond_ml);
+        int ia = ebase + bond_oa, ib = ebase + bond_ob;
+        ia = (bond_olda & (NC + 2)) | (~bond_olda & ia);      // the bonds before the move see the old monomer (entry NC + 2)
+        ib = (bond_oldb & (NC + 2)) | (~bond_oldb & ib);
+        const double2 xa = cA[ia], za = cB[ia], xb = cA[ib], zb = cB[ib];
         T3 na{xa.x, xa.y, za.x}, nb{xb.x, xb.y, zb.x};
         na.z = __hiloint2double(__double2hiint(na.z) ^ sign_a, __double2loint(na.z));   // refl_n!: n_z -> -n_z (lanes 5: a, 7: b)
         nb.z = __hiloint2double(__double2hiint(nb.z) ^ sign_b, __double2loint(nb.z));
@@ -424,19 +519,20 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
         // sweep of run/) only an accepted proposal needs it, and the commit takes the arc cosines then
         R psi = 0, ebend = 0;
         if (bend) {
-          psi = acos_r(fmin((R)1, fmax((R)-1, dt)));
+          psi = acos_tab(fmin((R)1, fmax((R)-1, dt)), kt);
           ebend = khalf * (psi - psi0) * (psi - psi0);
         }
         R epair = 0;
         if constexpr (EN == PSTAT_ISING)
-          epair = pair_term_fast(hb * (na.x + nb.x), hb * (na.y + nb.y), hb * (na.z + nb.z), ma.x, ma.y, ma.z, mb.x, mb.y, mb.z);
+          epair = pair_term_tab(hb * (na.x + nb.x), hb * (na.y + nb.y), hb * (na.z + nb.z), ma.x, ma.y, ma.z, mb.x, mb.y, mb.z, kt);
         const R pnew = (1 + dt) / 2;
-        const bool on = q < 2 ? hasL : (q < 4 ? hasR : (q < 6 ? on_u : on_l));
-        bond_on = on; bond_dt = dt;
-        const int grp = lane >> 3;
-        R w = grp == 0 ? psi : (grp == 1 ? ebend : epair);
-        w = (q & 1) ? w : -w;                // after minus before
-        w = on ? w : (R)0;                   // (a bond that does not exist may have computed anything)
+        // which bonds exist, as a per-lane 0 / -1 word out of a scalar bit mask (one v_bfe_i32); the sign (after minus before)
+        // and the existence mask are applied to the bits of the value (a bond that does not exist may have computed anything)
+        const uint32_t m8 = (hasL ? 3u : 0u) | (hasR ? 12u : 0u) | (on_u ? 48u : 0u) | (on_l ? 192u : 0u);
+        const int onm = __builtin_amdgcn_sbfe((int)m8, (unsigned)q, 1u);
+        bond_on = onm; bond_dt = dt;
+        const R wsel = sel_lanes(sel_lanes(epair, ebend, 0xFF00ull), psi, 0xFFull);     // lanes 0-7: psi, 8-15: bending, 16-: pair
+        const R w = __hiloint2double((__double2hiint(wsel) ^ bond_sign) & onm, __double2loint(wsel) & onm);
         const R tot = sum8(w);
         dpsi_all = lane_value<R>(tot, 0);
         dbend_all = lane_value<R>(tot, 8);
@@ -485,19 +581,19 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
         const R dpx = (m1.x - m0.x) + dp_flip.x, dpy = (m1.y - m0.y) + dp_flip.y, dpz = (m1.z - m0.z) + dp_flip.z;
         const R dc2 = ct1 * ct1 - ct0 * ct0;
         if (!bend) {                           // the bond angles of the accepted proposal, after minus before
-          const R psi = acos_r(fmin((R)1, fmax((R)-1, bond_dt)));
-          const R w = bond_on ? ((lane & 1) ? psi : -psi) : (R)0;
+          const R psi = acos_tab(fmin((R)1, fmax((R)-1, bond_dt)), kt);
+          const R w = __hiloint2double((__double2hiint(psi) ^ bond_sign) & bond_on, __double2loint(psi) & bond_on);
           dpsi_all = lane_value<R>(sum8(w), 0);
         }
         R dv = dpsi_all;                       // lane 8 (lanes >= 9 stay 0 + whatever: never read)
-        dv = lane == 7 ? dc2 : dv;
-        dv = lane == 6 ? dU : dv;
-        dv = lane == 5 ? dpz : dv;
-        dv = lane == 4 ? dpy : dv;
-        dv = lane == 3 ? dpx : dv;
-        dv = lane == 2 ? drz : dv;
-        dv = lane == 1 ? dry : dv;
-        dv = lane == 0 ? drx : dv;
+        dv = sel_lanes(dv, dc2, 1ull << 7);
+        dv = sel_lanes(dv, dU, 1ull << 6);
+        dv = sel_lanes(dv, dpz, 1ull << 5);
+        dv = sel_lanes(dv, dpy, 1ull << 4);
+        dv = sel_lanes(dv, dpx, 1ull << 3);
+        dv = sel_lanes(dv, drz, 1ull << 2);
+        dv = sel_lanes(dv, dry, 1ull << 1);
+        dv = sel_lanes(dv, drx, 1ull << 0);
         obsv += dv;
         usum += dus;
         lag_num = anum; lag_den = aden;
