@@ -1,5 +1,5 @@
 #!/bin/bash
-# Three of the reference's sweep drivers end to end through tools/run_sweep.py (one GPU), timed:
+# Three of the reference's sweep drivers (the phase scan at two ensemble sizes) end to end through tools/run_sweep.py (one GPU), timed:
 #   bash tools/reference_sweeps.sh <outdir>      -> <outdir>/*.log, <outdir>/*.csv (aggregated like scripts/aggregate_mcmc.jl)
 set -euo pipefail
 out=${1:-gpurun_out/sweeps}
@@ -17,6 +17,11 @@ t interacting_dielectric_study python tools/run_sweep.py "$w/interacting_dielect
 t K1_E0-kT-phase python tools/run_sweep.py "$w/K1_E0-kT-phase" --main mcmc_clustering_eap_chain --num-chains 16 --seed 2 \
   --axis b=1 --axis n=100 --axis Fx=0 --axis Fz=0 --axis kT='10^(-2:0.2:2)' --axis E0=0:0.2:5 --axis K1=1 --axis K2=0 --axis kappa=0 \
   --axis run=1:5 --name E0,K1,K2,kT,Fz,Fx,n,b,kappa,run:raw --aggregate "$out/K1_E0-kT-phase.csv" --aggregate-args '*.out,dielectric,true,true' \
+  -- --chain-type dielectric --energy-type Ising --num-steps 2500000 --burn-in 100000 -v 2 --stepout 250
+# the same sweep as the reference launches it: ONE chain per case (546 x 5 independent runs): one chain per wavefront (pstat_cluster_cw.hip)
+t K1_E0-kT-phase_1chain python tools/run_sweep.py "$w/K1_E0-kT-phase_1chain" --main mcmc_clustering_eap_chain --num-chains 1 --seed 2 \
+  --axis b=1 --axis n=100 --axis Fx=0 --axis Fz=0 --axis kT='10^(-2:0.2:2)' --axis E0=0:0.2:5 --axis K1=1 --axis K2=0 --axis kappa=0 \
+  --axis run=1:5 --name E0,K1,K2,kT,Fz,Fx,n,b,kappa,run:raw --aggregate "$out/K1_E0-kT-phase_1chain.csv" --aggregate-args '*.out,dielectric,true,true' \
   -- --chain-type dielectric --energy-type Ising --num-steps 2500000 --burn-in 100000 -v 2 --stepout 250
 # run/noninteracting-compare-with-clustering_2021-09-24.jl:19-33 -- 29 forces x 6 fields (BASELINE configs[1]'s grid), 1 000 000 steps, 64 chains per point
 t noninteracting_force_sweep python tools/run_sweep.py "$w/noninteracting_force_sweep" --main mcmc_eap_chain --num-chains 64 --seed 3 \
