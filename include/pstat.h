@@ -83,7 +83,11 @@ enum { PSTAT_RNG_MWC64X = 0, PSTAT_RNG_XOSHIRO128PP = 1 };
  *   PSTAT_MOVES_CLUSTER  mcmc_clustering_eap_chain.jl:268-279 -- the same move followed, on the trial
  *                        chain, by cluster_flip! (inc/eap_chain.jl:269-333); bending energy; two more
  *                        averagers (sum cos^2 theta, mean bond angle).  All four energies; the all-pairs
- *                        ones (interacting, cutoff) run one chain per wavefront, n <= 512. */
+ *                        ones (interacting, cutoff) run one chain per wavefront, n <= 512.  Non-interacting and
+ *                        Ising: one chain per lane, or -- f64 handles of up to 4 096 chains and sweeps of many cases
+ *                        of <= 16 chains each, n <= 256, MWC64X -- one chain per wavefront as well (a phase scan of
+ *                        the reference is 2 730 single-chain cases: 2.8 us per step instead of 29; pstat_launch_info.kernel
+ *                        names the choice).  Trajectories do not depend on it. */
 enum { PSTAT_MOVES_SINGLE = 0, PSTAT_MOVES_CLUSTER = 1 };
 
 /* Flattened pargs::Dict (mcmc_eap_chain.jl:155) -- the keys the force-ensemble step loop reads. */

@@ -1,14 +1,15 @@
 // pstat_cluster_cw.hip -- the step of mcmc_clustering_eap_chain.jl:268-311 (non-interacting and Ising energies, f64, MWC64X)
-// with ONE CHAIN PER WAVEFRONT: the kernel of SMALL ensembles, i.e. of the reference's own phase scans, which run one chain per
-// case (run/K1_E0-kT-phase.jl:19-45: 546 grid points x 5 runs).
+// with ONE CHAIN PER WAVEFRONT: the kernel of small ensembles and of sweeps of many small cases, i.e. of the reference's own
+// phase scans, which run one chain per case (run/K1_E0-kT-phase.jl:19-45: 546 grid points x 5 runs).
 //
 // Why a second mapping.  The chain-per-lane kernels (pstat_cluster_gm.hip) process 64 chains per instruction, but a step costs
 // them a fixed 4-5 us (dependent memory phases at one wave per SIMD) and, on an aligned chain (low kT, strong field: clusters
 // run over tens of monomers), 25-33 us -- a wave grows its clusters link by link and runs as long as the longest one among its
-// lanes.  A sweep of a few thousand chains over millions of steps is therefore bound by that SEQUENTIAL step time, with most of
-// the chip idle.  Here a step is a few hundred instructions of one wave whatever the cluster length:
+// lanes, and a launch as long as its slowest wave.  A sweep of a few thousand chains over millions of steps is therefore bound
+// by that SEQUENTIAL step time with most of the chip idle.  Here a step is ~400 vector instructions of one wave whatever the
+// cluster length, four waves share a SIMD, and the chip steps 2 730 chains in 2.8 us (chain per lane: 29 us):
 //   * the chain lives in LDS as cells (n_x, n_y | n_z, theta | phi) -- the reference's per-monomer cache, inc/eap_chain.jl:22-28
-//     -- and lane l owns monomers / links l, l + 64, ...;
+//     -- and lane l owns monomers / links l, l + 64, ... (M = 1, 2 or 4 of them: n <= 256);
 //   * cluster_flip! (inc/eap_chain.jl:269-333) grows in ONE pass: every lane forms the link probability of its own links and
 //     tests it against ITS draw of the stream.  The stream contract (oracle/eap_oracle.c cluster_flip) hands out the draws
 //     round by round, upper link then lower link while that end still grows, so a link's draw sits at a position that depends
@@ -20,15 +21,22 @@
 //     the state (M + 1) l outputs down the chain's stream, emits M + 1 words per step into LDS, and after the step every lane
 //     skips ahead by the number of words the step consumed -- one 64 x 64 -> 128-bit product with A^(d - 2) mod M from a
 //     constant table and two reduction steps T -> hi(T) + A lo32(T) (= T / 2^32 mod M, since A 2^32 = M + 1);
-//   * everything a step computes once per chain (the proposal's trigonometry, the eight bond terms before and after) is
-//     spread over lanes instead of being repeated in all of them: lanes 0-2 take the three sincos, lanes 0-7 the bonds
-//     (acos, bending and Ising pair term of (L,0) (L,1) (0,R) (1,R) and of the two boundary bonds before / after the
-//     reflection), gathered from LDS by per-lane cell index;
-//   * member sums (sum n_z, dipole components the reflection flips) are DPP tree sums over the lanes.
+//   * everything a step computes once per chain is spread over lanes instead of being repeated in all of them: lanes 0-2 take
+//     the three sincos, lanes 0-7 of every group of eight the eight bonds of the proposal (bond angle, bending and Ising pair
+//     term of (L,0) (L,1) (0,R) (1,R) and of the two boundary bonds before / after the reflection), gathered from LDS by
+//     per-lane cell index, and ONE signed tree sum over eight lanes delivers the three differences;
+//   * the ten observables of the microstate live across lanes 0-8 of one register: record! is two fused multiply-adds;
+//   * member sums (sum n_z; the dipole components a reflection flips only when the proposal is accepted) are DPP tree sums;
+//   * what a step needs but the register file should not hold: polynomial coefficients are read from an LDS table where a
+//     fused multiply-add wants them (a double constant otherwise costs two vector moves or a parked scalar pair), the object
+//     is built with machine LICM off (csrc/Makefile: immediates are re-formed at their use instead of being hoisted into ~90
+//     scalar registers that spill the step's own), pointers of the flush / spill sit in LDS, and the literal acceptance
+//     test is a function call.  Result: 128 registers, four waves per SIMD (measured 2 / 3 / 4 / 5 waves: 45 / 35 / 31 / 52 us
+//     per step of 43 680 chains, tools/ab_cw_waves.sh).
 // Results: the same trajectories as the oracle and the chain-per-lane kernels bit for bit (angles, generator state, acceptance
-// counts, step sizes); running sums differ in their last bits (order of the member sums), like every kernel pair here.
-// Chosen by cluster_chain_wave() below: f64, MWC64X, n <= 256, and an ensemble small enough that a wave per chain fills the
-// chip no deeper than a few waves per SIMD (PSTAT_F64_STATE=wave|lds|global overrides, for tests and experiments).
+// counts, step sizes; tests/fuzz_cluster_wave.py); running sums differ in their last bits (order of the member sums), like
+// every kernel pair here.  Chosen by cluster_chain_wave() below (PSTAT_F64_STATE=wave|lds|global overrides, for tests and
+// experiments); xoshiro128++ has no cheap skip-ahead and keeps the chain-per-lane kernels.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

@@ -28,6 +28,8 @@ run ${tag}_cluster_f64_ising tools/profile_cluster.py ising f64 5000 2
 # the same main in f32: cells in LDS (n = 100), and the in-memory home that 65 536 chains of n = 200 get by default
 run ${tag}_cluster_f32_ni tools/profile_cluster.py ni f32 5000 2
 run ${tag}_cluster_f32_mem_n200 tools/profile_cluster.py ni f32 5000 2 200
+# the clustering main one chain per wavefront: the reference's phase scan, 2 730 single-chain cases (run/K1_E0-kT-phase.jl)
+run ${tag}_cluster_cw_phase tools/profile_cluster_cw.py whole 1 20000 2
 # the all-pairs clustering main, n = 100
 run ${tag}_cluster_wave_f64_n100 tools/profile_cluster.py interacting f64 1000 2
 # the f64 non-interacting sweep at the phase-scan chain length (the kernel furthest below its roofline)

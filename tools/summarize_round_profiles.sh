@@ -15,6 +15,9 @@ $S gpurun_out/prof_${tag}_cfg_C3 profiles/$tag cfg_C3_sweep_f64_polar_n100 --ker
 $S gpurun_out/prof_${tag}_cfg_C4 profiles/$tag cfg_C4_interacting_f64_n64 --kernel interacting_kernel --updates 327680000 --record cfg_C4 > /dev/null
 $S gpurun_out/prof_${tag}_cfg_C5 profiles/$tag cfg_C5_sweep_f64_ising_n200_grid --kernel sweep_kernel --updates 1397760000 --record cfg_C5 > /dev/null
 $S gpurun_out/prof_${tag}_cluster_wave_f64_n100 profiles/$tag cluster_wave_f64_n100 --kernel cluster_wave --updates 16384000 > /dev/null
+if [ -d gpurun_out/prof_${tag}_cluster_cw_phase ]; then
+  $S gpurun_out/prof_${tag}_cluster_cw_phase profiles/$tag cluster_cw_phase_scan_n100 --kernel cluster_cw --updates 54600000 > /dev/null
+fi
 
 if [ -d gpurun_out/prof_${tag}_sweep_f64_ni_n200 ]; then
   $S gpurun_out/prof_${tag}_sweep_f64_ni_n200 profiles/$tag sweep_f64_ni_n200 --kernel sweep_kernel --updates 3276800000 > /dev/null
