@@ -31,8 +31,9 @@
 //     fused multiply-add wants them (a double constant otherwise costs two vector moves or a parked scalar pair), the object
 //     is built with machine LICM off (csrc/Makefile: immediates are re-formed at their use instead of being hoisted into ~90
 //     scalar registers that spill the step's own), pointers of the flush / spill sit in LDS, and the literal acceptance
-//     test is a function call.  Result: 128 registers, four waves per SIMD (measured 2 / 3 / 4 / 5 waves: 45 / 35 / 31 / 52 us
-//     per step of 43 680 chains, tools/ab_cw_waves.sh).
+//     test is a function call.  Result: 128 registers, four waves per SIMD (measured, per step of 43 680 chains: 34 us when
+//     the allocator is asked for two or three waves, 30 for four, 58 for five -- spills; 33 for four with machine LICM on;
+//     the first version, before any of this, 45; tools/ab_cw_waves.sh -> profiles/r04/experiments/ab_cw_waves.txt).
 // Results: the same trajectories as the oracle and the chain-per-lane kernels bit for bit (angles, generator state, acceptance
 // counts, step sizes; tests/fuzz_cluster_wave.py); running sums differ in their last bits (order of the member sums), like
 // every kernel pair here.  Chosen by cluster_chain_wave() below (PSTAT_F64_STATE=wave|lds|global overrides, for tests and
@@ -203,7 +204,7 @@ __device__ __attribute__((noinline)) bool literal_accept(const double dU, const 
 }
 
 #ifndef PSTAT_CW_WAVES
-#define PSTAT_CW_WAVES 4   // waves per SIMD asked of the register allocator (measured 2 / 3 / 4: 45 / 35 / 32 us per step of 43 680 chains, tools/ab_cw_waves.sh)
+#define PSTAT_CW_WAVES 4   // waves per SIMD asked of the register allocator (see the header)
 #endif
 
 template <int CT, int EN, int M>
