@@ -28,6 +28,9 @@ LDS, its figure is an EQUIVALENT rate (`equivalent: true`) and its traffic is ~1
 VALU issue (`valu`); `lds` is the third fraction SURVEY 8(d) asks for.  `traffic` / `valu.ops_per_update` come from
 the PMC passes in profiles/pmc_traffic.json and are used only if that file was collected on the kernel sources being
 benchmarked (sha256 stamp), else null / estimate.
+
+Beside the headline: `configs` (one measured entry per BASELINE configuration) and `phase_scan` (the clustering main on the
+ensemble shape the reference launches its phase scans with: 2 730 single-chain cases; microseconds per step).
 """
 from __future__ import annotations
 
@@ -217,6 +220,31 @@ def measure_configs(ps, torch, stream, pmc, headline, head_cpu, skip_cpu, budget
         log(f"config {cfg['id']}: {rate:.3e} updates/s ({kernel}); {time.perf_counter() - t_cfg:.1f} s")
         out.append(entry)
     return out
+
+
+def measure_phase_scan(ps, steps=20000):
+    """The reference's own phase scan as an ensemble (run/K1_E0-kT-phase.jl:17-45: 26 x 21 (E0, kT) points x 5 runs = 2 730
+    single-chain cases, clustering main, Ising, n = 100): microseconds per MC step of the whole ensemble, best of three timed
+    launches of `steps` steps after a warm-up.  Not the headline metric: the "next" row f3 + f4 of SURVEY.md section 8 on the
+    ensemble shape the reference launches it with."""
+    cases = [ps.default_params(n=100, E0=0.2 * (i // 21 % 26), K1=1.0, K2=0.0, kT=10 ** (-2 + 0.2 * (i % 21)), num_chains=1,
+                               precision=ps.F64, seed=1000 + i, move_set=ps.MOVES_CLUSTER, cluster_prob=0.5, energy_type=ps.ISING)
+             for i in range(2730)]
+    with ps.Ensemble(cases) as e:
+        e.advance(max(500, steps // 10))
+        e.sync()
+        best = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            e.advance(steps)
+            e.sync()
+            best = min(best, time.perf_counter() - t0)
+        info = e.launch_info()
+        return {"workload": "run/K1_E0-kT-phase.jl as the reference launches it: 546 (E0, kT) points x 5 runs = 2 730 single-chain cases, "
+                            "mcmc_clustering_eap_chain.jl step (single move + cluster_flip!), Ising, n = 100, f64",
+                "chains": len(cases), "mc_steps": steps, "us_per_step": round(best / steps * 1e6, 3),
+                "value": len(cases) * steps / best, "unit": "proposals/s", "kernel": info.kernel.decode(),
+                "workgroups": int(info.blocks), "workgroups_per_cu": int(info.blocks_per_cu), "timing": "host clock around advance + sync"}
 
 
 def parity_vs_cpu(ps, prec, n, chains, mc_steps, device, cpu_mean, cpu_se):
@@ -519,6 +547,7 @@ def main():
             headline = {"rate": args.chains * args.mc_steps / (kern_ms * 1e-3), "kernel_ms": kern_ms, "kernel": h["kernel"],
                         "check": h["check"]}
             out["configs"] = measure_configs(ps, torch, stream, pmc, headline, base, args.no_cpu_baseline, args.config_cpu_seconds)
+            out["phase_scan"] = measure_phase_scan(ps)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

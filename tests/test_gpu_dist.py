@@ -196,3 +196,6 @@ def test_bench_line_carries_one_measured_entry_per_baseline_config(tmp_path):
     assert c4["roofline"]["unit"] == "TFLOP/s" and c4["chains"] == 16384 and c4["n"] == 64 and c4["mc_steps"] == 20000
     assert cfgs[4]["chains"] == 546 * 128 and cfgs[4]["n"] == 200
     assert cfgs[1]["cpu_baseline"]["faithful"]["value"] == d["cpu_baseline"]["value"]       # C2 = the headline's own sample
+    scan = d["phase_scan"]            # the clustering main on the reference's own phase-scan ensemble: one chain per wavefront
+    assert scan["chains"] == 2730 and scan["workgroups"] == 2730 and "cluster_chain_wave_kernel" in scan["kernel"]
+    assert 0 < scan["us_per_step"] < 50 and scan["value"] == pytest.approx(2730 / (scan["us_per_step"] * 1e-6), rel=1e-3)
