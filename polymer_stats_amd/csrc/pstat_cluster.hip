@@ -106,7 +106,8 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
   R lag = (R)S.lag[c];                      // log(alpha) of the last accepted proposal of this mcmc() call
   const bool umb = umb_on != 0;
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
-  const R uref = umb ? (R)S.uref[c] : (R)0;
+  R uref = umb ? (R)S.uref[c] : (R)0;
+  bool regauged = false;
   double wnorm = umb ? S.wnorm[c] : 0.0;
   double sums[NSUMS];
 #pragma unroll
@@ -421,7 +422,27 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
       }
 
       // ---- record! x 10, mcmc_clustering_eap_chain.jl:243-244,310-311
-      const R wgt = umb ? exp_r(-(usum - uref) * wscale) : (R)1;
+      R wgt = 1;
+      if (umb) {
+        bool raise;
+        R wrel = umbrella_logw(usum, uref, wscale, raise);
+        if (__builtin_amdgcn_ballot_w64(raise) != 0) {   // the gauge rises to this configuration (pstat_math.h)
+          if (raise) {
+            const double f = exp_f64(-(double)wrel);
+            const R fr = (R)f;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) a1[q] *= fr;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) a2[q] *= fr;
+            accw *= fr;
+#pragma unroll
+            for (int q = 0; q < NSUMS; ++q) sums[q] *= f;
+            wnorm *= f;
+            uref = usum; regauged = true; wrel = 0;
+          }
+        }
+        wgt = exp_r(wrel);
+      }
       const R psim = psisum * inv_nm1;
       accw += wgt;
       a1[0] = fma_r(wgt, Orx, a1[0]); a1[1] = fma_r(wgt, Ory, a1[1]); a1[2] = fma_r(wgt, Orz, a1[2]);
@@ -490,6 +511,7 @@ __device__ __forceinline__ void run_cluster_segment(const SweepArgs &A, const De
   S.obs[OBS_C2 * C + c] = c2sum; S.obs[OBS_PSI * C + c] = psisum;
   S.lag[c] = lag;
   if (umb) S.wnorm[c] = wnorm;
+  if (regauged) S.uref[c] = (double)uref;
 #pragma unroll
   for (int q = 0; q < NSUMS; ++q) S.sums[q * C + c] = sums[q];
 }

@@ -322,7 +322,8 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
   bool lag_pending = false;
   const bool umb = umb_on != 0;
   const R wscale = umb ? (0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT : 0.0;
-  const R uref = umb ? S.uref[c] : 0.0;
+  R uref = umb ? S.uref[c] : 0.0;
+  bool regauged = false;
   double wnorm = umb ? S.wnorm[c] : 0.0;
   const R inv_nm1 = n > 1 ? 1.0 / (double)(n - 1) : 0.0;
 
@@ -616,7 +617,23 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
       __builtin_amdgcn_wave_barrier();
 
       // ---- record! x 10
-      const R wgt = umb ? exp_r(-(usum - uref) * wscale) : (R)1;
+      R wgt = 1;
+      if (umb) {
+        bool raise;
+        R wrel = umbrella_logw(usum, uref, wscale, raise);
+        if (raise) {   // (wave-uniform) the gauge rises to this configuration (pstat_math.h); every lane scales its own rows
+          const double f = exp_f64(-wrel);
+          double *const sums_c = cold->sums;
+          const int64_t Cc = cold->C;
+          const int r1 = lane < 3 ? lane : (lane < 6 ? lane + 3 : (lane == 6 ? (int)S_U : lane + 7));
+          const int r2 = lane < 3 ? lane + 3 : (lane < 6 ? lane + 6 : (int)S_USQ);
+          if (lane < 9) sums_c[(int64_t)r1 * Cc] *= f;
+          if (lane < 7) sums_c[(int64_t)r2 * Cc] *= f;
+          a1v *= f; a2v *= f; accw *= f; wnorm *= f;
+          uref = usum; regauged = true; wrel = 0;
+        }
+        wgt = exp_r(wrel);
+      }
       accw += wgt;
       a1v = fma_r(wgt, obsv, a1v);
       a2v = fma_r(wgt * obsv, obsv, a2v);
@@ -630,8 +647,8 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
       const int64_t Cc = cold->C;
       if (lane < 9) sums_c[(int64_t)r1 * Cc] += lane == 8 ? a1v * inv_nm1 : a1v;
       if (lane < 7) sums_c[(int64_t)r2 * Cc] += a2v;
+      wnorm += accw;
     }
-    wnorm += accw;
     left -= chunk;
     steps_seg += chunk;
 
@@ -685,6 +702,7 @@ __global__ __launch_bounds__(64, PSTAT_CW_WAVES) void cluster_cw_kernel(SweepArg
       ob[(int64_t)OBS_USUM * Cc] = usum;
       *cold->lag = lag_pending ? log_r(lag_num / lag_den) : lag;
       if (umb) *cold->wnorm = wnorm;
+      if (regauged) S.uref[c] = uref;
     }
   }
 }

@@ -155,7 +155,8 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
   bool lag_pending = false;
   const bool umb = umb_on != 0;
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
-  const R uref = umb ? (R)S.uref[c] : (R)0;
+  R uref = umb ? (R)S.uref[c] : (R)0;
+  bool regauged = false;
   double wnorm = umb ? S.wnorm[c] : 0.0;
   // (the f64 running sums stay in HBM: a block of FLUSH steps is added to them at a time -- 32 registers that the
   // step's window needs more)
@@ -607,7 +608,26 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
 
       PF_MARK(3);   // commit, its stores acknowledged
       // ---- record! x 10, mcmc_clustering_eap_chain.jl:243-244,310-311
-      const R wgt = umb ? exp_r(-(usum - uref) * wscale) : (R)1;
+      R wgt = 1;
+      if (umb) {
+        bool raise;
+        R wrel = umbrella_logw(usum, uref, wscale, raise);
+        if (__builtin_amdgcn_ballot_w64(raise) != 0) {   // the gauge rises to this configuration (pstat_math.h)
+          if (raise) {
+            const double f = exp_f64(-(double)wrel);
+            const R fr = (R)f;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) a1[q] *= fr;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) a2[q] *= fr;
+            accw *= fr;
+            for (int q = 0; q < NSUMS; ++q) S.sums[(int64_t)q * C + c] *= f;
+            wnorm *= f;
+            uref = usum; regauged = true; wrel = 0;
+          }
+        }
+        wgt = exp_r(wrel);
+      }
       const R psim = psisum * inv_nm1;
       accw += wgt;
       a1[0] = fma_r(wgt, Orx, a1[0]); a1[1] = fma_r(wgt, Ory, a1[1]); a1[2] = fma_r(wgt, Orz, a1[2]);
@@ -684,6 +704,7 @@ __device__ __forceinline__ void run_cluster_segment_gm(const SweepArgs &A, const
   S.obs[OBS_C2 * C + c] = c2sum; S.obs[OBS_PSI * C + c] = psisum;
   S.lag[c] = lag_pending ? log_r(lag_alpha) : lag;
   if (umb) S.wnorm[c] = wnorm;
+  if (regauged) S.uref[c] = (double)uref;
 }
 
 #ifndef PSTAT_GM_WAVES

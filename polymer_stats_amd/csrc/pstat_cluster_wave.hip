@@ -170,7 +170,8 @@ void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ 
   int nnan_seg = 0;   // proposals whose trial energy was NaN or +-Inf (1/r^3 at r -> 0)
   R lag = (R)S.lag[c];
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
-  const R uref = umb ? (R)S.uref[c] : (R)0;
+  R uref = umb ? (R)S.uref[c] : (R)0;
+  bool regauged = false;
   double wnorm = umb ? S.wnorm[c] : 0.0;
   // the f64 running sums stay in HBM: lane 0 adds a block of steps to them every FLUSH steps
   const R inv_nm1 = n > 1 ? (R)(1.0 / (double)(n - 1)) : (R)0;
@@ -293,7 +294,25 @@ void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ 
       }
 
       // ---- record! x 10, mcmc_clustering_eap_chain.jl:243-244,310-311
-      const R wgt = umb ? exp_r(-(cur.usum - uref) * wscale) : (R)1;
+      R wgt = 1;
+      if (umb) {
+        bool raise;
+        R wrel = umbrella_logw(cur.usum, uref, wscale, raise);
+        if (raise) {   // (wave-uniform) the gauge rises to this configuration (pstat_math.h)
+          const double f = exp_f64(-(double)wrel);
+          const R fr = (R)f;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) acc1[q] *= fr;
+#pragma unroll
+          for (int q = 0; q < 7; ++q) acc2[q] *= fr;
+          accw *= fr;
+          if (lane == 0)
+            for (int q = 0; q < NSUMS; ++q) S.sums[(int64_t)q * C + c] *= f;
+          wnorm *= f;
+          uref = cur.usum; regauged = true; wrel = 0;
+        }
+        wgt = exp_r(wrel);
+      }
       const R obs[9] = {cur.rx, cur.ry, cur.rz, cur.px, cur.py, cur.pz, cur.U, cur.c2sum, cur.psisum * inv_nm1};
       accw += wgt;
 #pragma unroll
@@ -358,6 +377,7 @@ void cluster_wave_kernel(SweepArgs A, DevState S, const CaseConst *__restrict__ 
     S.obs[OBS_C2 * C + c] = cur.c2sum; S.obs[OBS_PSI * C + c] = cur.psisum;
     S.lag[c] = lag;
     if (umb) S.wnorm[c] = wnorm;
+    if (regauged) S.uref[c] = (double)uref;
   }
 }
 

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(64, M == 8 ? PSTAT_IOCC_M8 :
   R lag = use_lag ? (R)S.lag[c] : (R)0;
   // umbrella sampling (inc/average.jl:104-124), as in the sweep kernel: only w - w(first config) matters
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
-  const R uref = umb ? (R)S.uref[c] : (R)0;
+  R uref = umb ? (R)S.uref[c] : (R)0;
+  bool regauged = false;
   double wnorm = umb ? S.wnorm[c] : 0.0;
   // the f64 running sums stay in HBM: lane 0 adds a block of steps to them every FLUSH steps (28 VGPRs
   // that the pair loop can use instead)
@@ -301,7 +302,20 @@ __global__ __launch_bounds__(64, M == 8 ? PSTAT_IOCC_M8 :
       // ---- record! x 8, mcmc_eap_chain.jl:327-328 (UmbrellaAverager: value += v / e^w, inc/average.jl:63-67)
       const R obs[7] = {rx, ry, rz, px, py, pz, U};
       if (umb) {
-        const R wgt = exp_r(-(usum - uref) * wscale);
+        bool raise;
+        R wrel = umbrella_logw(usum, uref, wscale, raise);
+        if (raise) {   // (wave-uniform) the gauge rises to this configuration (pstat_math.h)
+          const double f = exp_f64(-(double)wrel);
+          const R fr = (R)f;
+#pragma unroll
+          for (int q = 0; q < 7; ++q) { acc1[q] *= fr; acc2[q] *= fr; }
+          accw *= fr;
+          if (lane == 0)
+            for (int q = 0; q < NSUMS_BASE; ++q) S.sums[(int64_t)q * C + c] *= f;
+          wnorm *= f;
+          uref = usum; regauged = true; wrel = 0;
+        }
+        const R wgt = exp_r(wrel);
         accw += wgt;
 #pragma unroll
         for (int q = 0; q < 7; ++q) { acc1[q] = fma_r(wgt, obs[q], acc1[q]); acc2[q] = fma_r(wgt * obs[q], obs[q], acc2[q]); }
@@ -375,6 +389,7 @@ __global__ __launch_bounds__(64, M == 8 ? PSTAT_IOCC_M8 :
     S.obs[OBS_U * C + c] = U; S.obs[OBS_USUM * C + c] = usum;
     S.lag[c] = lag;
     if (umb) S.wnorm[c] = wnorm;
+    if (regauged) S.uref[c] = (double)uref;
   }
 }
 

@@ -241,7 +241,8 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   // every record is weighted by 1/e^w.  Only w - w(first configuration) is ever needed here.
   const bool umb = RARE && rare.umb;
   const R wscale = umb ? (R)((0.2 + 0.8 * exp(-(cc.Fx * cc.Fx + cc.Fz * cc.Fz) / cc.kT)) / cc.kT) : (R)0;
-  const R uref = umb ? (R)S.uref[c] : (R)0;
+  R uref = umb ? (R)S.uref[c] : (R)0;
+  bool regauged = false;
   double wnorm = umb ? S.wnorm[c] : 0.0;
   double sums[NSUMS_BASE];
 #pragma unroll
@@ -690,7 +691,23 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
 
       // ---- record! x 8, mcmc_eap_chain.jl:327-328 (every step, accepted or not)
       if (umb) {  // UmbrellaAverager: value += v / e^w, normalizer += 1 / e^w
-        const R wgt = exp_r(-(usum - uref) * wscale);
+        bool raise;
+        R wrel = umbrella_logw(usum, uref, wscale, raise);
+        if constexpr (RARE) {   // (umbrella sampling lives in the rare-options instantiation: nothing of this exists in the default one)
+          if (__builtin_amdgcn_ballot_w64(raise) != 0) {   // the gauge rises to this configuration (pstat_math.h)
+            if (raise) {
+              const double f = exp_f64(-(double)wrel);
+              const R fr = (R)f;
+              const P ff = {fr, fr};
+              a1rxy *= ff; a1pxy *= ff; a2rxy *= ff; a2pxy *= ff; a1z *= ff; a2z *= ff; a1U *= fr; a2U *= fr; accw *= fr;
+#pragma unroll
+              for (int q = 0; q < NSUMS_BASE; ++q) sums[q] *= f;
+              wnorm *= f;
+              uref = usum; regauged = true; wrel = 0;
+            }
+          }
+        }
+        const R wgt = exp_r(wrel);
         const P ww = {wgt, wgt};
         accw += wgt;
         a1rxy = pfma(ww, Orxy, a1rxy); a1pxy = pfma(ww, Opxy, a1pxy);
@@ -853,6 +870,7 @@ __device__ __forceinline__ void run_segment(const SweepArgs &A, const DevState &
   if constexpr (RARE) {
     S.lag[c] = lag;
     if (umb) S.wnorm[c] = wnorm;
+    if (regauged) S.uref[c] = (double)uref;
   }
 #pragma unroll
   for (int q = 0; q < NSUMS_BASE; ++q) S.sums[q * C + c] = sums[q];

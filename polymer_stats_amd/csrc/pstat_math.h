@@ -71,6 +71,23 @@ __device__ __forceinline__ double log_f64(const double x) {
   return v;                           // NaN in: frexp propagates it
 }
 
+// Umbrella sampling (inc/average.jl:52-124): records are weighted by 1 / e^w, w = sum(u) scale - log_gauge.  value / normaliser
+// does not depend on the gauge; the reference fixes it a priori (-lead n / 3 kT + Omega_initial), the device gauges a chain on
+// one of its own configurations (DevState::uref).  Neither is safe by itself: on a cold chain the reference's normaliser
+// underflows to 0 (NaN averages; seen in tests/fuzz_packed.py), and a configuration e^700 heavier than the gauged one --
+// one reflected cluster of a cold polar chain moves w by thousands -- overflows every sum (seen in tests/fuzz_cluster_wave.py).
+// So the gauge only ever RISES: a step whose configuration weighs more than e^T times the gauged one re-gauges the chain on it
+// before it is recorded -- every accumulated sum and the normaliser are multiplied by e^-w, its own weight becomes 1 --
+// and lighter configurations simply underflow, which is what their share of the average is.  umbrella_logw returns the
+// log-weight of the current configuration and whether the gauge must rise.
+template <typename R>
+__device__ __forceinline__ R umbrella_logw(const R usum, const R uref, const R wscale, bool &raise) {
+  const R wrel = -(usum - uref) * wscale;
+  constexpr R T = sizeof(R) == 4 ? (R)30 : (R)300;      // f32 weights and block sums live in floats (e^88 is their end)
+  raise = wrel > T;                                     // (false for a NaN)
+  return wrel;
+}
+
 __device__ __forceinline__ float exp_r(float x) { return __expf(x); }
 __device__ __forceinline__ double exp_r(double x) { return exp_f64(x); }
 __device__ __forceinline__ float log_r(float x) { return __logf(x); }

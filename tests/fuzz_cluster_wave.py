@@ -64,8 +64,8 @@ def run(trials, seed, log=print, home="wave"):
                     assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["phi"], o.final_phi), "angles"
                     assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total, "stream / count"
                     assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step, "steps"
-                    # (cold chains under --umbrella-sampling: the reference's weights exp(w - log_gauge) overflow where the
-                    # device's, gauged on the chain's first configuration, do not -- DESIGN.md 3.5; nothing to compare then)
+                    # (cold chains under --umbrella-sampling: the reference's weights exp(w - log_gauge) leave the range of a double
+                    # where the device's rising gauge keeps them inside -- DESIGN.md 3.5; nothing to compare then)
                     if np.all(np.isfinite(o.avg)) and 1e-290 < abs(o.norm) < 1e290:
                         np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-8, atol=1e-8)
                         x = e.chain_extras(c)

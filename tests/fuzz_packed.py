@@ -74,7 +74,7 @@ for trial in range(trials):
                 assert np.array_equal(g["rng"], o.rng) and g["nacc_total"] == o.nacc_total, "stream / count"
                 assert g["phi_step"] == o.phi_step and g["theta_step"] == o.theta_step, "steps"
                 # (--umbrella-sampling on a cold chain: the reference's weights exp(w - log_gauge) under- or overflow where the
-                # device's, gauged on the chain's first configuration, stay representable -- DESIGN.md 3.5.  Trial 701 of seed 1:
+                # device's, whose gauge rises with the chain, stay representable -- DESIGN.md 3.5.  Trial 701 of seed 1:
                 # oracle normaliser 1.5e-306 and 0.0, device 2.4e7 and 2.4e3.  Nothing to compare then.)
                 if np.all(np.isfinite(o.avg)) and 1e-290 < abs(o.norm) < 1e290:
                     np.testing.assert_allclose(g["sums"] / g["normalizer"], o.avg, rtol=1e-7, atol=1e-7)

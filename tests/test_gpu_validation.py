@@ -328,3 +328,49 @@ def test_nonfinite_energy_counter_counts_every_such_proposal(ps, oracle, monkeyp
         e.advance(nsteps)
         s = e.summary()
         assert s.nan_rejects == 0 and s.chains_collapsed == 0 and s.acceptance_ratio > 0.1
+
+
+@pytest.mark.parametrize("home", ["lds", "global", "wave"])
+def test_umbrella_weights_are_regauged_on_a_cold_drifting_chain(ps, oracle, monkeypatch, home):
+    """--umbrella-sampling weights records by 1 / e^w; value / normaliser does not depend on the gauge of w, but a double does:
+    on a cold chain relaxing from an aligned start the first-configuration gauge overflows (seen in tests/fuzz_cluster_wave.py:
+    NaN averages on trajectories that equal the oracle's).  The kernels re-gauge at block boundaries (umbrella_regauge,
+    csrc/pstat_math.h): averages stay finite and equal the oracle's, whose a-priori gauge happens to hold here."""
+    monkeypatch.setenv("PSTAT_F64_STATE", home)
+    kw = dict(n=128, E0=2.9683420157514435, K1=0.2620076967924292, K2=0.22902565388456103, mu=0.583542905988572,
+              kT=0.032115462164346804, Fz=-0.1148105231949863, Fx=0.0, b=0.6435975332131777, chain_type=1, energy_type=0, umbrella=1,
+              cluster_prob=0.0, steps_per_adjust=137, adj_scale=1.1, seed=337374529627, use_x0=1, x0_phi=2.30492766419305,
+              x0_theta=0.4408010319490809, dx0_phi=0.05, dx0_theta=0.05)
+    nsteps = 2500
+    op, pp = both(nsteps, num_chains=3, precision=ps.F64, **kw)
+    pp.move_set = ps.MOVES_CLUSTER
+    with ps.Ensemble(pp) as e:
+        e.advance(900); e.advance(nsteps - 900)
+        for c in range(3):
+            o = oracle.run(op, chain_id=c, mode="cluster", trace=True)
+            g = e.chain_state(c)
+            assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["rng"], o.rng)
+            avg = g["sums"] / g["normalizer"]
+            assert np.all(np.isfinite(avg)) and np.isfinite(g["normalizer"]) and g["normalizer"] > 0, (home, c, g["normalizer"])
+            assert np.all(np.isfinite(o.avg)) and 1e-290 < o.norm < 1e290      # (the reference's gauge holds on this one)
+            np.testing.assert_allclose(avg, o.avg, rtol=1e-8, atol=1e-8)
+        s = e.summary()
+        assert np.all(np.isfinite(np.array(s.avg))) and np.all(np.isfinite(np.array(s.stderr)))
+
+
+def test_umbrella_weights_survive_where_the_references_underflow(ps, oracle):
+    """The other direction (found by tests/fuzz_packed.py): on this cold n = 114 chain the reference's a-priori gauge sends its
+    normaliser to 1.5e-306 and then 0 -- NaN averages -- within 900 steps; the device's averages stay finite (same trajectories)."""
+    kw = dict(n=114, E0=1.983535541035057, K1=1.0913260760266574, K2=0.42644128996853004, kT=0.3939373987076173, Fz=1.4196626815208542,
+              Fx=-0.5148310727063605, b=0.5014461273162807, seed=565127474194, umbrella=1, steps_per_adjust=400, adj_scale=1.1, uniform_bits=23)
+    op, pp = both(900, num_chains=7, precision=ps.F64, **kw)
+    with ps.Ensemble(pp) as e:
+        e.advance(900)
+        lost = 0
+        for c in range(7):
+            o = oracle.run(op, chain_id=c, mode="fast", trace=True)
+            g = e.chain_state(c)
+            assert np.array_equal(g["theta"], o.final_theta) and np.array_equal(g["rng"], o.rng)
+            assert np.all(np.isfinite(g["sums"] / g["normalizer"])) and g["normalizer"] > 1e-200, (c, g["normalizer"])
+            lost += int(not (np.all(np.isfinite(o.avg)) and abs(o.norm) > 1e-290))
+        assert lost >= 1          # (otherwise this test no longer shows what it is meant to)
