@@ -268,7 +268,8 @@ int pstat_summary_from_reduction(const double red[PSTAT_NRED], int64_t steps_per
  * doubles, radians; sums: the 16 per-chain running sums in rolling.csv order;
  * counters: {accepted_total, steps_recorded, nacc_window, natt_window};
  * steps: {phi_step, theta_step, normalizer}, normalizer = the averagers' denominator for this chain
- * (steps recorded, or the sum of 1/e^w under umbrella sampling up to a per-chain constant factor). */
+ * (steps recorded, or the sum of 1/e^w under umbrella sampling up to a per-chain factor that the sums share: the gauge
+ * of w rises with the heaviest configuration a chain has visited, so that neither overflows -- DESIGN.md 3.5). */
 int pstat_chain_state(pstat_handle *h, int64_t chain, double *angles /* [2n] */,
                       double sums[PSTAT_NOBS], int64_t counters[4], double steps[3],
                       uint32_t rng[4]);

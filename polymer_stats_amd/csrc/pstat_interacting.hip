@@ -34,7 +34,9 @@ namespace pstat {
 
 // M consecutive monomers per lane: lane l owns monomers l*M .. l*M + M-1 (n <= 64 M).
 // (f64, M = 1 sits at the 256-VGPR boundary: ask for two waves per SIMD so that it stays on the good side)
-template <typename R, typename G, int CT, int M>
+// UMB: --umbrella-sampling (its weights and the rising gauge, pstat_math.h) is compiled into its own instantiation: as a run-time
+// option its few extra live values cost the plain kernel 3 % at n = 64 (three waves per SIMD, a register budget with no slack)
+template <typename R, typename G, int CT, int M, bool UMB>
 // f32 waves per SIMD asked of the register allocator for M = 1, 2, 4 (measured, 16 384 chains: M = 1 at
 // 4 instead of the 3 it takes by itself +2 % at n = 64, +10 % at n = 23; M = 4 at 2 instead of 1 +16 % at
 // n = 200; M = 2 at 3 instead of 2 loses 4 % at n = 100)
@@ -64,8 +66,9 @@ __global__ __launch_bounds__(64, M == 8 ? PSTAT_IOCC_M8 :
                                  sizeof(R) == 8 ? (M == 1 ? PSTAT_IOCC_F64M1 : (M == 2 ? PSTAT_IOCC_F64M2 : PSTAT_IOCC_F64M4))
                                                 : (M == 1 ? PSTAT_IOCC_M1 : (M == 2 ? PSTAT_IOCC_M2 : PSTAT_IOCC_M4))) void interacting_kernel(SweepArgs A, DevState S,
                                                          const CaseConst *__restrict__ cases,
-                                                         int do_flips, int use_lag, int umb,
+                                                         int do_flips, int use_lag,
                                                          int reinit_mode /* 0 | 1 metropolis | 2 forced */) {
+  constexpr bool umb = UMB;
   using AG = Ang<R>;
   using R4 = typename std::conditional<sizeof(R) == 4, float4, double4>::type;
   using R2 = typename Vec2<R>::type;
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(64, M == 8 ? PSTAT_IOCC_M8 :
       }
       // ---- record! x 8, mcmc_eap_chain.jl:327-328 (UmbrellaAverager: value += v / e^w, inc/average.jl:63-67)
       const R obs[7] = {rx, ry, rz, px, py, pz, U};
-      if (umb) {
+      if constexpr (UMB) {
         bool raise;
         R wrel = umbrella_logw(usum, uref, wscale, raise);
         if (raise) {   // (wave-uniform) the gauge rises to this configuration (pstat_math.h)
@@ -393,15 +396,19 @@ __global__ __launch_bounds__(64, M == 8 ? PSTAT_IOCC_M8 :
   }
 }
 
-using InterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int, int, int);
+using InterFn = void (*)(SweepArgs, DevState, const CaseConst *, int, int, int);
 
+template <typename R, typename G, bool UMB>
+static InterFn pick_interacting_mu(const LaunchCfg &cfg, int64_t n) {
+  const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
+  if (n <= 64) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 1, UMB> : interacting_kernel<R, G, PSTAT_POLAR, 1, UMB>;
+  if (n <= 128) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 2, UMB> : interacting_kernel<R, G, PSTAT_POLAR, 2, UMB>;
+  if (n <= 256) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 4, UMB> : interacting_kernel<R, G, PSTAT_POLAR, 4, UMB>;
+  return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 8, UMB> : interacting_kernel<R, G, PSTAT_POLAR, 8, UMB>;
+}
 template <typename R, typename G>
 static InterFn pick_interacting_m(const LaunchCfg &cfg, int64_t n) {
-  const bool diel = cfg.chain_type == PSTAT_DIELECTRIC;
-  if (n <= 64) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 1> : interacting_kernel<R, G, PSTAT_POLAR, 1>;
-  if (n <= 128) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 2> : interacting_kernel<R, G, PSTAT_POLAR, 2>;
-  if (n <= 256) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 4> : interacting_kernel<R, G, PSTAT_POLAR, 4>;
-  return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 8> : interacting_kernel<R, G, PSTAT_POLAR, 8>;
+  return cfg.umbrella ? pick_interacting_mu<R, G, true>(cfg, n) : pick_interacting_mu<R, G, false>(cfg, n);
 }
 
 // Two objects are built from this file (csrc/Makefile): -DPSTAT_IPART=1 holds the f32 instantiations
@@ -426,7 +433,7 @@ hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const De
                               const CaseConst *cases, int reinit_mode, hipStream_t stream) {
   InterFn fn = pick_interacting(cfg, a.n);
   hipLaunchKernelGGL(fn, dim3((unsigned)s.C), dim3(64), 0, stream, a, s, cases, cfg.do_flips,
-                     (cfg.lag || reinit_mode) ? 1 : 0, cfg.umbrella, reinit_mode);
+                     (cfg.lag || reinit_mode) ? 1 : 0, reinit_mode);
   return hipGetLastError();
 }
 
