@@ -406,27 +406,33 @@ static InterFn pick_interacting_mu(const LaunchCfg &cfg, int64_t n) {
   if (n <= 256) return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 4, UMB> : interacting_kernel<R, G, PSTAT_POLAR, 4, UMB>;
   return diel ? interacting_kernel<R, G, PSTAT_DIELECTRIC, 8, UMB> : interacting_kernel<R, G, PSTAT_POLAR, 8, UMB>;
 }
-template <typename R, typename G>
-static InterFn pick_interacting_m(const LaunchCfg &cfg, int64_t n) {
-  return cfg.umbrella ? pick_interacting_mu<R, G, true>(cfg, n) : pick_interacting_mu<R, G, false>(cfg, n);
+template <typename R, bool UMB>
+static InterFn pick_interacting_ru(const LaunchCfg &cfg, int64_t n) {
+  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_interacting_mu<R, Xoshiro128pp, UMB>(cfg, n)
+                                           : pick_interacting_mu<R, Mwc64x, UMB>(cfg, n);
 }
 
-// Two objects are built from this file (csrc/Makefile): -DPSTAT_IPART=1 holds the f32 instantiations
-// (statistical parity only), -DPSTAT_IPART=2 the f64 ones (bit parity with the oracle) and the launchers; both with
-// -ffp-contract=fast -- the f64 proposal arithmetic is fenced, see the note in the Makefile.  Without the macro: everything in one object.
+// Four objects are built from this file (csrc/Makefile, parallel build): -DPSTAT_IPART=1 holds the f32 instantiations
+// (statistical parity only), =2 the f64 ones (bit parity with the oracle) and the launchers, =3 / =4 their umbrella-sampling
+// twins; all with -ffp-contract=fast -- the f64 proposal arithmetic is fenced, see the note in the Makefile.  Without the
+// macro: everything in one object.
 #if !defined(PSTAT_IPART) || PSTAT_IPART == 1
-InterFn pick_interacting_f32(const LaunchCfg &cfg, int64_t n) {
-  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_interacting_m<float, Xoshiro128pp>(cfg, n)
-                                           : pick_interacting_m<float, Mwc64x>(cfg, n);
-}
+InterFn pick_interacting_f32(const LaunchCfg &cfg, int64_t n) { return pick_interacting_ru<float, false>(cfg, n); }
+#endif
+#if !defined(PSTAT_IPART) || PSTAT_IPART == 3
+InterFn pick_interacting_f32_umb(const LaunchCfg &cfg, int64_t n) { return pick_interacting_ru<float, true>(cfg, n); }
+#endif
+#if !defined(PSTAT_IPART) || PSTAT_IPART == 4
+InterFn pick_interacting_f64_umb(const LaunchCfg &cfg, int64_t n) { return pick_interacting_ru<double, true>(cfg, n); }
 #endif
 #if !defined(PSTAT_IPART) || PSTAT_IPART == 2
 InterFn pick_interacting_f32(const LaunchCfg &cfg, int64_t n);
+InterFn pick_interacting_f32_umb(const LaunchCfg &cfg, int64_t n);
+InterFn pick_interacting_f64_umb(const LaunchCfg &cfg, int64_t n);
 
 static InterFn pick_interacting(const LaunchCfg &cfg, int64_t n) {
-  if (cfg.precision != PSTAT_F64) return pick_interacting_f32(cfg, n);
-  return cfg.rng == PSTAT_RNG_XOSHIRO128PP ? pick_interacting_m<double, Xoshiro128pp>(cfg, n)
-                                           : pick_interacting_m<double, Mwc64x>(cfg, n);
+  if (cfg.precision != PSTAT_F64) return cfg.umbrella ? pick_interacting_f32_umb(cfg, n) : pick_interacting_f32(cfg, n);
+  return cfg.umbrella ? pick_interacting_f64_umb(cfg, n) : pick_interacting_ru<double, false>(cfg, n);
 }
 
 hipError_t launch_interacting(const LaunchCfg &cfg, const SweepArgs &a, const DevState &s,
